@@ -1,0 +1,115 @@
+/*
+ * zernike_hip.h -- C ABI of libzernike_hip.so, the MI355X (gfx950) implementation of
+ * motif-learn's per-patch Zernike-moment hot path.
+ *
+ * The reference (jiadongdan/motif-learn, pure Python) has no native interface; its boundary is
+ * the Python class `mtflearn.features.ZPs`.  Each entry point below replaces the arithmetic of
+ * one reference method and is what a maintainer would bind with ctypes from inside that method
+ * (binding stub: INTEGRATION.md):
+ *
+ *   zk_plan_create            <- ZPs.__init__ keeps `self.polynomials`            (_zps.py:48-50)
+ *   zk_transform_patches      <- ZPs._transform_dot_product                       (_zps.py:146-157)
+ *   zk_transform_frame        <- ZPs._transform_fft_convolve                      (_zps.py:159-193)
+ *   zk_*_dev                  <- same, operands already resident in HBM (bench / multi-GPU)
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative code
+ *     (-hipError_t for runtime failures, ZK_E_* for argument errors) and never throws;
+ *     zk_last_error_string() describes the most recent failure on the calling thread.
+ *   - the caller owns every host buffer; inputs are read-only, outputs are C-contiguous
+ *     float64; no pointer is retained after the call returns.  Device memory owned by the
+ *     library lives inside the plan and is released by zk_plan_destroy().
+ *   - a plan is bound to one device and is not thread-safe (one stream per plan).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails.
+ */
+#ifndef ZERNIKE_HIP_H
+#define ZERNIKE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_ABI_VERSION 1
+
+/* element type of the image / patch operand */
+#define ZK_F32 0
+#define ZK_F64 1
+
+/* argument-error codes (runtime failures are -hipError_t, i.e. -1 .. -1999) */
+#define ZK_E_BADARG   (-10001)
+#define ZK_E_NODEVICE (-10002)
+#define ZK_E_NOMEM    (-10003)
+
+/* kernel selection, for tests and A/B measurements (default ZK_PATH_AUTO) */
+#define ZK_PATH_AUTO    0
+#define ZK_PATH_GENERIC 1   /* any size / n_max, unfolded direct summation            */
+#define ZK_PATH_FAST    2   /* parity-folded, LDS-staged; fails if the plan has none   */
+
+typedef struct zk_plan zk_plan;
+
+/* Library / device discovery. */
+int         zk_abi_version(void);
+int         zk_device_count(void);            /* >= 0, or a negative code               */
+const char* zk_last_error_string(void);
+
+/*
+ * Create a plan for one (size, n_poly) basis on `device`.
+ *   basis : host, (n_poly, size, size) float64, C order -- ZPs.polynomials      (_zps.py:90)
+ *   n, m  : host, (n_poly) int32 radial order / azimuthal frequency per basis function, in
+ *           the order of `basis`                                                  (_zps.py:74-81)
+ * The plan uploads the disk-masked basis, pre-divided by the reference's normalising area
+ * pi*size^2/4 (_zps.py:154,177), and when the basis has the x/y mirror parities of real
+ * Zernike functions also a 4-quadrant parity-folded table used by the fast kernels.
+ */
+int  zk_plan_create(int size, int n_poly, const int32_t* n, const int32_t* m,
+                    const double* basis, int device, zk_plan** out);
+void zk_plan_destroy(zk_plan* plan);
+
+/* Introspection: 1 if the plan holds the parity-folded tables / a fast kernel for `dtype`. */
+int zk_plan_has_fast(const zk_plan* plan, int mode /*0 patches, 1 frame*/, int dtype);
+/* Number of pixels inside the unit disk (rho <= 1 as evaluated by the caller's basis). */
+int zk_plan_disk_pixels(const zk_plan* plan);
+/* Force a kernel family (ZK_PATH_*). */
+int zk_plan_set_path(zk_plan* plan, int path);
+
+/*
+ * Batch of patches (reference _zps.py:146-157):
+ *   out[p, j] = sum_{r,c} patches[p, r, c] * basis[j, r, c] / (pi size^2 / 4)
+ *   patches : (N, size, size) of `dtype`, C order;  out : (N, n_poly) float64.
+ * Host variant copies in/out through staging buffers owned by the plan.
+ */
+int zk_transform_patches(zk_plan* plan, const void* patches_host, int dtype, int64_t n_patches,
+                         double* out_host);
+int zk_transform_patches_dev(zk_plan* plan, const void* patches_dev, int dtype,
+                             int64_t n_patches, double* out_dev, void* hip_stream);
+
+/*
+ * Dense frame (reference _zps.py:159-193, i.e. fftconvolve(mode='same') * (-1)^n / area):
+ *   out[j, i, k] = sum_{r,c} pad(image)[i - ea + r, k - ea + c] * basis[j, r, c] / (pi size^2/4)
+ *   with eb = (size-1)/2, ea = size-1-eb and zero padding outside the image.
+ *   image : (H, W) of `dtype`;  out : (n_poly, H, W) float64 (moment-major, as the reference).
+ * The *_dev variant computes output rows [row0, row0+n_rows) only and writes them to
+ * out_dev laid out as (n_poly, n_rows, W) -- the row-band shard of one GPU; the image operand
+ * is always the whole frame.
+ */
+int zk_transform_frame(zk_plan* plan, const void* image_host, int dtype, int64_t height,
+                       int64_t width, double* out_host);
+int zk_transform_frame_dev(zk_plan* plan, const void* image_dev, int dtype, int64_t height,
+                           int64_t width, int64_t row0, int64_t n_rows, double* out_dev,
+                           void* hip_stream);
+
+/*
+ * Kernel timing with HIP events on the stream the kernels are launched on.
+ * zk_plan_profile(plan, 1) brackets every subsequent kernel launch with an event pair;
+ * zk_plan_profile_read() synchronises, returns the launch count and summed kernel
+ * milliseconds since the last read, and resets the counters.
+ */
+int zk_plan_profile(zk_plan* plan, int enable);
+int zk_plan_profile_read(zk_plan* plan, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZERNIKE_HIP_H */

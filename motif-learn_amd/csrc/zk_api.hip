@@ -1,0 +1,272 @@
+// zk_api.hip -- host side of libzernike_hip.so: plans, tables, dispatch, C ABI (include/zernike_hip.h).
+#include <math.h>
+#include <string.h>
+
+#include <new>
+
+#include "zk_internal.h"
+
+// ------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_last_error = "";
+
+int zk_fail(int code, const std::string& what) {
+  g_last_error = what;
+  return code;
+}
+
+int zk_hip_fail(hipError_t e, const char* what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  (void)hipGetLastError();  // clear the sticky error
+  return -(int)e;
+}
+
+extern "C" const char* zk_last_error_string(void) { return g_last_error.c_str(); }
+extern "C" int zk_abi_version(void) { return ZK_ABI_VERSION; }
+
+extern "C" int zk_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e == hipErrorNoDevice) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (e != hipSuccess) return zk_hip_fail(e, "hipGetDeviceCount");
+  return n;
+}
+
+// ------------------------------------------------------------------------------------
+// profiling: one event pair per launch, resolved lazily
+// ------------------------------------------------------------------------------------
+int zk_prof_begin(zk_plan* p, hipStream_t s) {
+  if (!p->profile) return 0;
+  if (p->ev_used + 2 > p->ev_pool.size()) {
+    for (int k = 0; k < 2; ++k) {
+      hipEvent_t e;
+      ZK_HIP(hipEventCreate(&e));
+      p->ev_pool.push_back(e);
+    }
+  }
+  ZK_HIP(hipEventRecord(p->ev_pool[p->ev_used], s));
+  return 0;
+}
+
+int zk_prof_end(zk_plan* p, hipStream_t s) {
+  if (!p->profile) return 0;
+  ZK_HIP(hipEventRecord(p->ev_pool[p->ev_used + 1], s));
+  p->ev_used += 2;
+  return 0;
+}
+
+extern "C" int zk_plan_profile(zk_plan* p, int enable) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  p->profile = enable != 0;
+  return 0;
+}
+
+extern "C" int zk_plan_profile_read(zk_plan* p, int64_t* launches, double* total_ms) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  ZK_HIP(hipSetDevice(p->device));
+  for (size_t k = 0; k + 1 < p->ev_used; k += 2) {
+    ZK_HIP(hipEventSynchronize(p->ev_pool[k + 1]));
+    float ms = 0.f;
+    ZK_HIP(hipEventElapsedTime(&ms, p->ev_pool[k], p->ev_pool[k + 1]));
+    p->prof_ms += ms;
+    p->prof_launches += 1;
+  }
+  p->ev_used = 0;
+  if (launches) *launches = p->prof_launches;
+  if (total_ms) *total_ms = p->prof_ms;
+  p->prof_launches = 0;
+  p->prof_ms = 0.0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------
+static int build_generic_tables(zk_plan* p, const double* basis) {
+  const int K = p->size, NP = p->n_poly;
+  const double inv_area = 1.0 / (M_PI * (double)K * (double)K / 4.0);
+  std::vector<int2> pix;
+  for (int r = 0; r < K; ++r)
+    for (int c = 0; c < K; ++c) {
+      bool any = false;
+      for (int j = 0; j < NP && !any; ++j) any = basis[((size_t)j * K + r) * K + c] != 0.0;
+      if (any) pix.push_back(make_int2(r, c));
+    }
+  p->npx = (int)pix.size();
+  p->n_chunks = (NP + ZK_GEN_CHUNK - 1) / ZK_GEN_CHUNK;
+  std::vector<double> tab((size_t)p->n_chunks * p->npx * ZK_GEN_CHUNK, 0.0);
+  for (int j = 0; j < NP; ++j) {
+    const int c = j / ZK_GEN_CHUNK, l = j % ZK_GEN_CHUNK;
+    for (int t = 0; t < p->npx; ++t)
+      tab[((size_t)c * p->npx + t) * ZK_GEN_CHUNK + l] =
+          basis[((size_t)j * K + pix[t].x) * K + pix[t].y] * inv_area;
+  }
+  if (p->npx == 0) return 0;
+  ZK_HIP(hipMalloc((void**)&p->d_pix, pix.size() * sizeof(int2)));
+  ZK_HIP(hipMemcpy(p->d_pix, pix.data(), pix.size() * sizeof(int2), hipMemcpyHostToDevice));
+  ZK_HIP(hipMalloc((void**)&p->d_gen_tab, tab.size() * sizeof(double)));
+  ZK_HIP(hipMemcpy(p->d_gen_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" void zk_plan_destroy(zk_plan* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  zk_fold_free(p);
+  for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+  if (p->d_pix) (void)hipFree(p->d_pix);
+  if (p->d_gen_tab) (void)hipFree(p->d_gen_tab);
+  if (p->d_in) (void)hipFree(p->d_in);
+  if (p->d_out) (void)hipFree(p->d_out);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+extern "C" int zk_plan_create(int size, int n_poly, const int32_t* n, const int32_t* m,
+                              const double* basis, int device, zk_plan** out) {
+  if (!out) return zk_fail(ZK_E_BADARG, "out is null");
+  *out = nullptr;
+  if (size <= 0 || n_poly <= 0 || !basis || !n || !m)
+    return zk_fail(ZK_E_BADARG, "size and n_poly must be positive and basis/n/m non-null");
+  if (size > 4096) return zk_fail(ZK_E_BADARG, "size too large");
+  const int ndev = zk_device_count();
+  if (ndev < 0) return ndev;
+  if (ndev == 0) return zk_fail(ZK_E_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return zk_fail(ZK_E_BADARG, "device index out of range");
+  zk_plan* p = new (std::nothrow) zk_plan();
+  if (!p) return zk_fail(ZK_E_NOMEM, "out of host memory");
+  p->size = size;
+  p->n_poly = n_poly;
+  p->device = device;
+  p->n.assign(n, n + n_poly);
+  p->m.assign(m, m + n_poly);
+  int rc = 0;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) rc = zk_hip_fail(e, "hipSetDevice");
+  if (!rc) {
+    e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) rc = zk_hip_fail(e, "hipStreamCreate");
+  }
+  if (!rc) rc = build_generic_tables(p, basis);
+  if (!rc) rc = zk_fold_build(p, basis);
+  if (rc) {
+    std::string keep = g_last_error;
+    zk_plan_destroy(p);
+    g_last_error = keep;
+    return rc;
+  }
+  *out = p;
+  return 0;
+}
+
+extern "C" int zk_plan_has_fast(const zk_plan* p, int mode, int dtype) {
+  if (!p) return 0;
+  return mode == 0 ? (int)zk_fast_patches_available(p, dtype) : (int)zk_fast_frame_available(p, dtype);
+}
+
+extern "C" int zk_plan_disk_pixels(const zk_plan* p) { return p ? p->npx : 0; }
+
+extern "C" int zk_plan_set_path(zk_plan* p, int path) {
+  if (!p || path < ZK_PATH_AUTO || path > ZK_PATH_FAST) return zk_fail(ZK_E_BADARG, "bad path");
+  p->path = path;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------
+static int check_dtype(int dtype) {
+  if (dtype != ZK_F32 && dtype != ZK_F64) return zk_fail(ZK_E_BADARG, "dtype must be ZK_F32 or ZK_F64");
+  return 0;
+}
+
+static size_t elem_size(int dtype) { return dtype == ZK_F32 ? 4 : 8; }
+
+extern "C" int zk_transform_patches_dev(zk_plan* p, const void* patches, int dtype, int64_t n_patches,
+                                        double* out, void* hip_stream) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  int rc = check_dtype(dtype);
+  if (rc) return rc;
+  if (n_patches < 0) return zk_fail(ZK_E_BADARG, "negative patch count");
+  if (n_patches == 0) return 0;
+  if (!patches || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
+  ZK_HIP(hipSetDevice(p->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : p->stream;
+  const bool fast = zk_fast_patches_available(p, dtype);
+  if (p->path == ZK_PATH_FAST && !fast) return zk_fail(ZK_E_BADARG, "plan has no fast patch kernel for this shape");
+  if (fast && p->path != ZK_PATH_GENERIC) return zk_launch_fast_patches(p, patches, dtype, n_patches, out, s);
+  return zk_launch_generic_patches(p, patches, dtype, n_patches, out, s);
+}
+
+extern "C" int zk_transform_frame_dev(zk_plan* p, const void* image, int dtype, int64_t H, int64_t W,
+                                      int64_t row0, int64_t n_rows, double* out, void* hip_stream) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  int rc = check_dtype(dtype);
+  if (rc) return rc;
+  if (H <= 0 || W <= 0 || H > 0x3fffffff || W > 0x3fffffff) return zk_fail(ZK_E_BADARG, "bad frame shape");
+  if (row0 < 0 || n_rows < 0 || row0 + n_rows > H) return zk_fail(ZK_E_BADARG, "row band outside the frame");
+  if (n_rows == 0) return 0;
+  if (!image || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
+  ZK_HIP(hipSetDevice(p->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : p->stream;
+  const bool fast = zk_fast_frame_available(p, dtype);
+  if (p->path == ZK_PATH_FAST && !fast) return zk_fail(ZK_E_BADARG, "plan has no fast frame kernel for this shape");
+  if (fast && p->path != ZK_PATH_GENERIC) return zk_launch_fast_frame(p, image, dtype, H, W, row0, n_rows, out, s);
+  return zk_launch_generic_frame(p, image, dtype, H, W, row0, n_rows, out, s);
+}
+
+static int ensure(void** buf, size_t* have, size_t need) {
+  if (*have >= need) return 0;
+  if (*buf) {
+    ZK_HIP(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+  }
+  ZK_HIP(hipMalloc(buf, need));
+  *have = need;
+  return 0;
+}
+
+extern "C" int zk_transform_patches(zk_plan* p, const void* patches_host, int dtype, int64_t n_patches,
+                                    double* out_host) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  int rc = check_dtype(dtype);
+  if (rc) return rc;
+  if (n_patches < 0) return zk_fail(ZK_E_BADARG, "negative patch count");
+  if (n_patches == 0) return 0;
+  if (!patches_host || !out_host) return zk_fail(ZK_E_BADARG, "null host pointer");
+  ZK_HIP(hipSetDevice(p->device));
+  const size_t in_bytes = (size_t)n_patches * p->size * p->size * elem_size(dtype);
+  const size_t out_bytes = (size_t)n_patches * p->n_poly * sizeof(double);
+  if ((rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes))) return rc;
+  if ((rc = ensure((void**)&p->d_out, &p->d_out_bytes, out_bytes))) return rc;
+  ZK_HIP(hipMemcpyAsync(p->d_in, patches_host, in_bytes, hipMemcpyHostToDevice, p->stream));
+  if ((rc = zk_transform_patches_dev(p, p->d_in, dtype, n_patches, p->d_out, p->stream))) return rc;
+  ZK_HIP(hipMemcpyAsync(out_host, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
+  ZK_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+extern "C" int zk_transform_frame(zk_plan* p, const void* image_host, int dtype, int64_t H, int64_t W,
+                                  double* out_host) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  int rc = check_dtype(dtype);
+  if (rc) return rc;
+  if (H <= 0 || W <= 0) return zk_fail(ZK_E_BADARG, "bad frame shape");
+  if (!image_host || !out_host) return zk_fail(ZK_E_BADARG, "null host pointer");
+  ZK_HIP(hipSetDevice(p->device));
+  const size_t in_bytes = (size_t)H * W * elem_size(dtype);
+  const size_t out_bytes = (size_t)p->n_poly * H * W * sizeof(double);
+  if ((rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes))) return rc;
+  if ((rc = ensure((void**)&p->d_out, &p->d_out_bytes, out_bytes))) return rc;
+  ZK_HIP(hipMemcpyAsync(p->d_in, image_host, in_bytes, hipMemcpyHostToDevice, p->stream));
+  if ((rc = zk_transform_frame_dev(p, p->d_in, dtype, H, W, 0, H, p->d_out, p->stream))) return rc;
+  ZK_HIP(hipMemcpyAsync(out_host, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
+  ZK_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}

@@ -1,0 +1,97 @@
+// zk_fold.h -- parity-folded Zernike tables and the device-side accumulation step shared by
+// the fast kernels (zk_fast_frame.hip, zk_fast_patches.hip).
+//
+// Every real Zernike function on the symmetric grid linspace(-1,1,K)^2 (reference
+// _zps.py:68-72) is even or odd under the column mirror c -> K-1-c and under the row mirror
+// r -> K-1-r:  cos(m t) has x-parity (-1)^m and is y-even;  sin(|m| t) has x-parity -(-1)^m
+// and is y-odd (_zps.py:85-88).  So the K*K-term inner product of a window with one basis
+// function collapses onto the quadrant r,c < ceil(K/2):
+//     sum = sum_{r,c in quadrant} V[r,c] * F_class(r,c),
+//     F_EE = (a+b)+(c+d)  F_OE = (a-b)+(c-d)  F_EO = (a+b)-(c+d)  F_OO = (a-b)-(c-d)
+// with a,b,c,d the window pixels at (r,c), (r,c'), (r',c), (r',c').  The four folded values
+// cost 8 adds per quadrant pixel and are shared by all N_poly functions, which cuts the f64
+// FMA count 4x.  For float32 pixels the folds are exact in float64.
+#pragma once
+
+#include "zk_internal.h"
+
+// ---- compile-time description of the full real Zernike set 0..NMAX -----------------------
+// Accumulators are kept in class order [EE | OE | EO | OO], ascending reference index j
+// inside a class.
+template <int NMAX>
+struct zk_set {
+  static constexpr int count(int cls) {
+    int k = 0;
+    for (int n = 0; n <= NMAX; ++n)
+      for (int m = -n; m <= n; m += 2) {
+        const int am = m < 0 ? -m : m;
+        const int c = m >= 0 ? ((am & 1) ? ZK_OE : ZK_EE) : ((am & 1) ? ZK_EO : ZK_OO);
+        k += (c == cls);
+      }
+    return k;
+  }
+  static constexpr int EE = count(ZK_EE), OE = count(ZK_OE), EO = count(ZK_EO), OO = count(ZK_OO);
+  static constexpr int NP = EE + OE + EO + OO;
+};
+
+inline int zk_class_of(int m) {
+  const int am = m < 0 ? -m : m;
+  return m >= 0 ? ((am & 1) ? ZK_OE : ZK_EE) : ((am & 1) ? ZK_EO : ZK_OO);
+}
+
+// One unit of the batch kernel: 16 folded pixels of one row pair, as 4 folded granules.
+struct zk_unit {
+  int32_t run_off[4];  // byte offsets inside a patch of the source runs (RUN=8 uses [0],[1])
+  int32_t mask;        // bit q set: folded granule q has a pixel inside the disk
+  int32_t tab_first;   // index of the unit's first active granule in the granule table
+  int32_t pad[2];
+};
+
+struct zk_fold_tables {
+  int kernel_nmax = -1;     // instantiated NMAX the tables are padded to (>= the plan's n_max)
+  int np_kernel = 0;        // zk_set<kernel_nmax>::NP
+  int32_t* d_colmap = nullptr;  // [np_kernel] class-ordered slot -> output column, -1 = padding
+
+  // frame kernel: active quadrant pixels in row-major order
+  int n_fpx = 0;
+  int tile_pitch = 0;       // elements per LDS tile row the offsets were built for
+  int4* d_fpx_off = nullptr;    // [n_fpx] tile element offsets of a, b, c, d
+  double* d_ftab = nullptr;     // [n_fpx][np_kernel], class order, scaled by weight/area
+
+  // batch kernel (float32 patches, K % 16 == 0, K >= 32)
+  int run = 0;              // granules per source run: 8 (K == 32) or 4
+  int n_units = 0;
+  zk_unit* d_units = nullptr;   // [n_units]
+  double* d_ptab = nullptr;     // [active granules][4][np_kernel]
+};
+
+#ifdef __HIPCC__
+// Tables are read through the constant address space: a wave-uniform load from it is always a
+// scalar load (s_load -> SGPR), whatever stores, LDS-DMA or asm barriers surround it.
+#define ZK_CONST __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const ZK_CONST T* zk_const(const T* p) {
+  return (const ZK_CONST T*)p;
+}
+
+// acc[slot] += F_class(slot) * bt[slot] for every slot of the NMAX set; bt is wave-uniform, so
+// its elements arrive through scalar loads and feed v_fma_f64 as SGPR operands.
+template <int NMAX>
+__device__ __forceinline__ void zk_fold_fma(double (&acc)[zk_set<NMAX>::NP], double a, double b, double c,
+                                            double d, const ZK_CONST double* bt) {
+  using S = zk_set<NMAX>;
+  const double s1 = a + b, d1 = a - b, s2 = c + d, d2 = c - d;
+  const double fee = s1 + s2, foe = d1 + d2, feo = s1 - s2, foo = d1 - d2;
+#pragma unroll
+  for (int i = 0; i < S::EE; ++i) acc[i] = __builtin_fma(fee, bt[i], acc[i]);
+#pragma unroll
+  for (int i = 0; i < S::OE; ++i) acc[S::EE + i] = __builtin_fma(foe, bt[S::EE + i], acc[S::EE + i]);
+#pragma unroll
+  for (int i = 0; i < S::EO; ++i)
+    acc[S::EE + S::OE + i] = __builtin_fma(feo, bt[S::EE + S::OE + i], acc[S::EE + S::OE + i]);
+#pragma unroll
+  for (int i = 0; i < S::OO; ++i)
+    acc[S::EE + S::OE + S::EO + i] =
+        __builtin_fma(foo, bt[S::EE + S::OE + S::EO + i], acc[S::EE + S::OE + S::EO + i]);
+}
+#endif

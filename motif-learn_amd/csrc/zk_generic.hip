@@ -1,0 +1,104 @@
+// zk_generic.hip -- unfolded direct-summation kernels for any (size, n_max, dtype).
+//
+// One lane owns one output unit (a patch in batch mode, an output pixel in frame mode) and
+// walks the disk pixels in row-major order.  The loop index is wave-uniform, so the pixel
+// coordinates and the ZK_GEN_CHUNK basis values of the current pixel come in through scalar
+// loads (SGPR operands of v_fma_f64) and cost no vector-memory or LDS bandwidth; the only
+// per-lane traffic is the pixel itself.  In frame mode consecutive lanes read consecutive
+// image columns (coalesced, L2-resident frame); in batch mode lanes are one patch apart,
+// which is TCP-inefficient -- this kernel is the correctness fallback for shapes the
+// folded kernels (zk_fast_*.hip) do not cover, not the measured hot path.
+//
+// Arithmetic: out = sum_t pixel(t) * (basis[j][t] / area), accumulated in float64 in disk
+// order -- the definition both reference paths approximate (_zps.py:155, :165-178).
+#include "zk_internal.h"
+
+namespace {
+
+template <typename T, int MODE>  // MODE 0: batch of patches, 1: dense frame
+__global__ __launch_bounds__(256) void zk_generic_kernel(
+    const T* __restrict__ in, double* __restrict__ out, const int2* __restrict__ pix,
+    const double* __restrict__ tab, int npx, int n_poly, int n_chunks, int size, long long n_units,
+    int H, int W, int row0) {
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = u < n_units;
+  const int ea = size - 1 - (size - 1) / 2;
+  int oi = 0, ok = 0;             // frame mode: output pixel
+  const T* base = in;             // batch mode: this lane's patch
+  if (MODE == 1) {
+    const long long il = live ? u / W : 0;
+    ok = live ? (int)(u - il * W) : 0;
+    oi = row0 + (int)il;
+  } else {
+    base = in + (live ? u : 0) * (long long)size * size;
+  }
+
+  for (int c = 0; c < n_chunks; ++c) {
+    double acc[ZK_GEN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < ZK_GEN_CHUNK; ++j) acc[j] = 0.0;
+    const double* __restrict__ row = tab + (size_t)c * npx * ZK_GEN_CHUNK;
+    for (int t = 0; t < npx; ++t) {
+      const int2 rc = pix[t];
+      double f;
+      if (MODE == 1) {
+        const int ii = oi - ea + rc.x;
+        const int kk = ok - ea + rc.y;
+        const bool inside = live && ii >= 0 && ii < H && kk >= 0 && kk < W;
+        f = inside ? (double)in[(long long)ii * W + kk] : 0.0;
+      } else {
+        f = (double)base[rc.x * size + rc.y];
+      }
+      const double* __restrict__ b = row + (size_t)t * ZK_GEN_CHUNK;
+#pragma unroll
+      for (int j = 0; j < ZK_GEN_CHUNK; ++j) acc[j] = __builtin_fma(f, b[j], acc[j]);
+    }
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < ZK_GEN_CHUNK; ++j) {
+        const int jj = c * ZK_GEN_CHUNK + j;
+        if (jj < n_poly) {
+          if (MODE == 1) {
+            // (n_poly, n_rows, W): u already enumerates (row, col) of the band
+            out[(long long)jj * n_units + u] = acc[j];
+          } else {
+            out[u * n_poly + jj] = acc[j];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MODE>
+int launch(zk_plan* p, const void* in, int dtype, long long n_units, int H, int W, int row0,
+           double* out, hipStream_t s) {
+  if (n_units <= 0) return 0;
+  const long long blocks = (n_units + 255) / 256;
+  if (blocks > 0x7fffffffLL) return zk_fail(ZK_E_BADARG, "too many units for one launch");
+  int rc = zk_prof_begin(p, s);
+  if (rc) return rc;
+  if (dtype == ZK_F32) {
+    hipLaunchKernelGGL((zk_generic_kernel<float, MODE>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       (const float*)in, out, p->d_pix, p->d_gen_tab, p->npx, p->n_poly, p->n_chunks,
+                       p->size, n_units, H, W, row0);
+  } else {
+    hipLaunchKernelGGL((zk_generic_kernel<double, MODE>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       (const double*)in, out, p->d_pix, p->d_gen_tab, p->npx, p->n_poly, p->n_chunks,
+                       p->size, n_units, H, W, row0);
+  }
+  ZK_HIP(hipGetLastError());
+  return zk_prof_end(p, s);
+}
+
+}  // namespace
+
+int zk_launch_generic_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,
+                              hipStream_t s) {
+  return launch<0>(p, in, dtype, n_patches, 0, 0, 0, out, s);
+}
+
+int zk_launch_generic_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,
+                            int64_t n_rows, double* out, hipStream_t s) {
+  return launch<1>(p, in, dtype, n_rows * W, (int)H, (int)W, (int)row0, out, s);
+}

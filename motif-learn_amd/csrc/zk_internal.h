@@ -1,0 +1,77 @@
+// zk_internal.h -- shared declarations of libzernike_hip (not part of the public ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "zernike_hip.h"
+
+#define ZK_GEN_CHUNK 16  // basis functions per accumulation pass of the generic kernel
+
+// Parity class of a real Zernike function under the mirrors x -> -x and y -> -y
+// (cos(m t): x-parity (-1)^m, y-even; sin(|m| t): x-parity -(-1)^m, y-odd).
+enum zk_class { ZK_EE = 0, ZK_OE = 1, ZK_EO = 2, ZK_OO = 3 };  // <x parity><y parity>, E even / O odd
+
+struct zk_fold_tables;  // zk_fold.h
+
+struct zk_plan {
+  int size = 0;
+  int n_poly = 0;
+  int device = 0;
+  int path = ZK_PATH_AUTO;
+  std::vector<int32_t> n, m;
+
+  // ---- generic (unfolded) tables -------------------------------------------------
+  int npx = 0;                   // pixels with a non-zero basis value (the rho<=1 disk)
+  int n_chunks = 0;              // ceil(n_poly / ZK_GEN_CHUNK)
+  int2* d_pix = nullptr;         // [npx] (row, col) of each disk pixel, row-major order
+  double* d_gen_tab = nullptr;   // [n_chunks][npx][ZK_GEN_CHUNK], basis/area, zero padded
+
+  // ---- parity-folded tables (fast kernels) ----------------------------------------
+  zk_fold_tables* fold = nullptr;  // nullptr when the basis lacks the mirror parities
+
+  // ---- execution state -------------------------------------------------------------
+  hipStream_t stream = nullptr;  // owned; host-variant calls and default for *_dev
+  void* d_in = nullptr;          // staging for the host variants
+  size_t d_in_bytes = 0;
+  double* d_out = nullptr;
+  size_t d_out_bytes = 0;
+
+  bool profile = false;
+  std::vector<hipEvent_t> ev_pool;  // pairs: [2k] start, [2k+1] stop
+  size_t ev_used = 0;               // events handed out since the last read
+  int64_t prof_launches = 0;
+  double prof_ms = 0.0;
+};
+
+// error plumbing (zk_api.hip)
+int zk_fail(int code, const std::string& what);
+int zk_hip_fail(hipError_t e, const char* what);
+#define ZK_HIP(call)                                   \
+  do {                                                 \
+    hipError_t zk_e_ = (call);                         \
+    if (zk_e_ != hipSuccess) return zk_hip_fail(zk_e_, #call); \
+  } while (0)
+
+// profiling brackets (zk_api.hip)
+int zk_prof_begin(zk_plan* p, hipStream_t s);
+int zk_prof_end(zk_plan* p, hipStream_t s);
+
+// kernel launchers; each returns 0 or a negative code.
+int zk_launch_generic_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,
+                              hipStream_t s);
+int zk_launch_generic_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,
+                            int64_t n_rows, double* out, hipStream_t s);
+
+// fast path (zk_fold.hip / zk_fast_*.hip)
+int zk_fold_build(zk_plan* p, const double* basis);  // fills p->fold or leaves it null
+void zk_fold_free(zk_plan* p);
+bool zk_fast_patches_available(const zk_plan* p, int dtype);
+bool zk_fast_frame_available(const zk_plan* p, int dtype);
+int zk_launch_fast_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,
+                           hipStream_t s);
+int zk_launch_fast_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,
+                         int64_t n_rows, double* out, hipStream_t s);

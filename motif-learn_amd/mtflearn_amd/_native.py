@@ -1,0 +1,162 @@
+"""ctypes binding of ``libzernike_hip.so`` (C ABI: ``include/zernike_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/Makefile`` into
+``mtflearn_amd/lib/``.  There is deliberately no CPU fallback here: if the shared object is
+missing, or no HIP device is visible, every compute call raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+ZK_F32, ZK_F64 = 0, 1
+PATH_AUTO, PATH_GENERIC, PATH_FAST = 0, 1, 2
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libzernike_hip.so")
+
+# every symbol include/zernike_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "zk_abi_version": (c_int, []),
+    "zk_device_count": (c_int, []),
+    "zk_last_error_string": (c_char_p, []),
+    "zk_plan_create": (c_int, [c_int, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_double),
+                               c_int, POINTER(c_void_p)]),
+    "zk_plan_destroy": (None, [c_void_p]),
+    "zk_plan_has_fast": (c_int, [c_void_p, c_int, c_int]),
+    "zk_plan_disk_pixels": (c_int, [c_void_p]),
+    "zk_plan_set_path": (c_int, [c_void_p, c_int]),
+    "zk_transform_patches": (c_int, [c_void_p, c_void_p, c_int, c_int64, POINTER(c_double)]),
+    "zk_transform_patches_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "zk_transform_frame": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, POINTER(c_double)]),
+    "zk_transform_frame_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
+                                       c_void_p, c_void_p]),
+    "zk_plan_profile": (c_int, [c_void_p, c_int]),
+    "zk_plan_profile_read": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C motif-learn_amd/csrc` (hipcc, --offload-arch=gfx950). "
+            "mtflearn_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().zk_last_error_string()
+    return msg.decode() if msg else ""
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code}: {last_error()}")
+
+
+def device_count():
+    n = load().zk_device_count()
+    if n < 0:
+        raise RuntimeError(f"zk_device_count failed with code {n}: {last_error()}")
+    return n
+
+
+def dtype_code(dtype):
+    """ZK_F32 / ZK_F64 for the two element types the kernels read natively, else None."""
+    if dtype == np.float32:
+        return ZK_F32
+    if dtype == np.float64:
+        return ZK_F64
+    return None
+
+
+class Plan:
+    """Owns one ``zk_plan`` (device tables for one basis on one GPU)."""
+
+    def __init__(self, basis, n, m, device=0):
+        lib = load()
+        basis = np.ascontiguousarray(basis, dtype=np.float64)
+        self.n_poly, self.size = int(basis.shape[0]), int(basis.shape[1])
+        self.device = int(device)
+        n32 = np.ascontiguousarray(n, dtype=np.int32)
+        m32 = np.ascontiguousarray(m, dtype=np.int32)
+        if device_count() == 0:
+            raise RuntimeError("no HIP device visible: mtflearn_amd computes on MI355X only "
+                               "(there is no CPU fallback)")
+        handle = c_void_p()
+        check(lib.zk_plan_create(self.size, self.n_poly, n32.ctypes.data_as(POINTER(c_int32)),
+                                 m32.ctypes.data_as(POINTER(c_int32)),
+                                 basis.ctypes.data_as(POINTER(c_double)), self.device, byref(handle)),
+              "zk_plan_create")
+        self._h = handle
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.zk_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # -- introspection / control -------------------------------------------------------
+    def has_fast(self, mode, dtype_code_):
+        return bool(self._lib.zk_plan_has_fast(self._h, mode, dtype_code_))
+
+    @property
+    def disk_pixels(self):
+        return self._lib.zk_plan_disk_pixels(self._h)
+
+    def set_path(self, path):
+        check(self._lib.zk_plan_set_path(self._h, path), "zk_plan_set_path")
+
+    def profile(self, enable=True):
+        check(self._lib.zk_plan_profile(self._h, int(enable)), "zk_plan_profile")
+
+    def profile_read(self):
+        launches, ms = c_int64(), c_double()
+        check(self._lib.zk_plan_profile_read(self._h, byref(launches), byref(ms)), "zk_plan_profile_read")
+        return launches.value, ms.value
+
+    # -- host-buffer entry points --------------------------------------------------------
+    def transform_patches(self, patches):
+        code = dtype_code(patches.dtype)
+        out = np.empty((patches.shape[0], self.n_poly), dtype=np.float64)
+        check(self._lib.zk_transform_patches(self._h, patches.ctypes.data_as(c_void_p), code,
+                                             patches.shape[0], out.ctypes.data_as(POINTER(c_double))),
+              "zk_transform_patches")
+        return out
+
+    def transform_frame(self, image):
+        code = dtype_code(image.dtype)
+        h, w = image.shape
+        out = np.empty((self.n_poly, h, w), dtype=np.float64)
+        check(self._lib.zk_transform_frame(self._h, image.ctypes.data_as(c_void_p), code, h, w,
+                                           out.ctypes.data_as(POINTER(c_double))),
+              "zk_transform_frame")
+        return out
+
+    # -- device-pointer entry points (bench / multi-GPU harness) ------------------------------
+    def transform_patches_dev(self, patches_ptr, code, n_patches, out_ptr, stream=0):
+        check(self._lib.zk_transform_patches_dev(self._h, c_void_p(patches_ptr), code, n_patches,
+                                                 c_void_p(out_ptr), c_void_p(stream)),
+              "zk_transform_patches_dev")
+
+    def transform_frame_dev(self, image_ptr, code, height, width, row0, n_rows, out_ptr, stream=0):
+        check(self._lib.zk_transform_frame_dev(self._h, c_void_p(image_ptr), code, height, width, row0,
+                                               n_rows, c_void_p(out_ptr), c_void_p(stream)),
+              "zk_transform_frame_dev")

@@ -1,0 +1,168 @@
+"""``ZPs`` -- Zernike-moment transformer whose ``transform`` runs on MI355X.
+
+Drop-in for ``mtflearn.features.ZPs`` (reference ``mtflearn/features/_zps.py:11-197``): same
+constructor, attributes (``n_max``, ``size``, ``n``, ``m``, ``polynomials``), methods, sklearn
+behaviour (``get_params`` / ``clone`` / ``repr``), warning and error messages, output container
+(:class:`zmoments`) and output dtype (float64).  What differs is where the arithmetic happens:
+
+* 3-D input ``(N, size, size)``  -> ``zk_transform_patches``  (reference ``_zps.py:146-157``, a GEMM)
+* 2-D input ``(H, W)``           -> ``zk_transform_frame``    (reference ``_zps.py:159-193``, FFT
+  convolution) -- here an exact direct sum, so it does not carry the single-precision FFT noise
+  the reference has on float32 images.
+
+Both are hand-written HIP kernels behind the C ABI of ``include/zernike_hip.h``; there is no CPU
+fallback -- without a HIP device ``transform`` raises ``RuntimeError``.  The basis itself is built
+on the host exactly as the reference builds it (``_zps.py:52-90``), so ``polynomials`` is
+bit-identical.
+
+Device selection: environment variable ``MTFLEARN_AMD_DEVICE`` (default 0), read at first use.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+
+import numpy as np
+from scipy.special import factorial
+from sklearn.base import BaseEstimator, TransformerMixin
+
+from .. import _native
+from .moments import zmoments
+
+__all__ = ["ZPs"]
+
+
+def _radial_terms(n, abs_m):
+    """[(coefficient, power)] of R_n^{|m|}: coefficient (-1)^k (n-k)! / (k! a! b!), power n-2k."""
+    half_sum, half_diff = (n + abs_m) // 2, (n - abs_m) // 2
+    terms = []
+    for k in range(half_diff + 1):
+        upper = (-1) ** k * factorial(n - k)
+        lower = factorial(k) * factorial(half_sum - k) * factorial(half_diff - k)
+        terms.append((upper / lower, n - 2 * k))
+    return terms
+
+
+class ZPs(BaseEstimator, TransformerMixin):
+    """Zernike polynomial basis of radial order <= ``n_max`` on a ``size`` x ``size`` grid.
+
+    Parameters
+    ----------
+    n_max : int
+        Maximum radial order.
+    size : int
+        Side of the polynomial grid / of the patches the moments are taken over.
+    """
+
+    def __init__(self, n_max: int, size: int):
+        if n_max < 0:
+            raise ValueError("n_max must be non-negative.")
+        if size <= 0:
+            raise ValueError("size must be positive.")
+        if n_max > size:
+            raise ValueError(
+                f"n_max={n_max} exceeds size={size}. This will produce "
+                f"meaningless results. Use n_max <= {size//2} for accurate moments.")
+        if n_max > size / 2:
+            warnings.warn(
+                f"n_max={n_max} exceeds recommended limit of size/2≈{size // 2}. "
+                f"High-order Zernike moments may suffer from aliasing and numerical "
+                f"errors. For accurate results, use n_max <= {size//2}; for maximum "
+                f"stability, use n_max <= {size // 2}.",
+                UserWarning, stacklevel=2)
+        self.n_max = n_max
+        self.size = size
+        self.n, self.m, self.polynomials = self._generate_polynomials()
+        self._plan = None
+
+    # ------------------------------------------------------------------ basis (host)
+    def _generate_polynomials(self):
+        """(n, m, V): V[j] = R_n^{|m|}(rho) sqrt(2(n+1)/(1+[m==0])) {cos(m t) | sin(|m| t)} on
+        ``linspace(-1, 1, size)^2``, zero outside rho <= 1; n ascending, then m ascending.
+        Same floating-point operations, in the same order, as reference ``_zps.py:52-90``."""
+        grid = np.linspace(-1, 1, self.size)
+        xs, ys = np.meshgrid(grid, grid)
+        rho = np.sqrt(xs ** 2 + ys ** 2)
+        theta = np.arctan2(ys, xs)
+        inside = rho <= 1
+        radial_cache = {}
+        orders, freqs, stack = [], [], []
+        for n in range(self.n_max + 1):
+            for m in range(-n, n + 1, 2):
+                key = (n, abs(m))
+                if key not in radial_cache:
+                    radial = np.zeros_like(rho)
+                    for coef, power in _radial_terms(n, abs(m)):
+                        radial += coef * rho ** power
+                    radial_cache[key] = radial
+                scale = np.sqrt(2 * (n + 1) / (1 + (m == 0)))
+                masked = np.where(inside, radial_cache[key] * scale, 0)
+                angular = np.sin(-m * theta) if m < 0 else np.cos(m * theta)
+                orders.append(n)
+                freqs.append(m)
+                stack.append(masked * angular)
+        return np.array(orders), np.array(freqs), np.array(stack)
+
+    def get_polynomials(self) -> np.ndarray:
+        return self.polynomials
+
+    # ------------------------------------------------------------------ sklearn surface
+    def fit(self, X, y=None):
+        """No-op (stateless transformer), kept for sklearn pipelines."""
+        return self
+
+    def fit_transform(self, X, y=None):
+        return self.fit(X).transform(X)
+
+    # ------------------------------------------------------------------ device plan
+    def _device_plan(self):
+        if self._plan is None:
+            device = int(os.environ.get("MTFLEARN_AMD_DEVICE", "0"))
+            self._plan = _native.Plan(self.polynomials, self.n, self.m, device=device)
+        return self._plan
+
+    def __getstate__(self):
+        state = dict(super().__getstate__())
+        state["_plan"] = None  # device handles do not pickle / deepcopy
+        return state
+
+    @staticmethod
+    def _device_operand(images):
+        """C-contiguous float32 / float64 view or copy of a real-valued array."""
+        if np.iscomplexobj(images):
+            raise TypeError("complex images are not supported by the HIP kernels")
+        if images.dtype not in (np.float32, np.float64):
+            images = images.astype(np.float64)  # ints, bool, float16: exact in float64
+        return np.ascontiguousarray(images)
+
+    # ------------------------------------------------------------------ transform
+    def transform(self, images) -> zmoments:
+        """Zernike moments of a batch of patches (3-D input) or of every ``size`` x ``size``
+        window of a frame (2-D input, zero-padded 'same' alignment)."""
+        images = np.asarray(images)
+        if images.ndim == 2:
+            return self._transform_frame(images)
+        if images.ndim == 3:
+            return self._transform_patches(images)
+        raise ValueError("Images must be 2D or 3D array.")
+
+    def _transform_patches(self, images):
+        _, height, width = images.shape
+        if height != self.size or width != self.size:
+            raise ValueError(
+                f"For batch processing, image size ({height}x{width}) must match "
+                f"polynomial size ({self.size}x{self.size})")
+        if images.shape[0] == 0:
+            data = np.empty((0, len(self.n)), dtype=np.float64)
+        else:
+            data = self._device_plan().transform_patches(self._device_operand(images))
+        return zmoments(data=data, n=self.n, m=self.m, patch_size=self.size)
+
+    def _transform_frame(self, image):
+        height, width = image.shape
+        if height < self.size or width < self.size:
+            raise ValueError(
+                f"For FFT convolution, image size ({height}x{width}) must be at least "
+                f"as large as polynomial size ({self.size}x{self.size})")
+        data = self._device_plan().transform_frame(self._device_operand(image))
+        return zmoments(data=data, n=self.n, m=self.m, patch_size=self.size)

@@ -1,0 +1,296 @@
+"""Parity of the HIP path (through the C ABI) with the reference: golden vectors captured from the
+reference, the CPU oracle on seeded inputs, and size-independent properties at BASELINE sizes.
+
+Tolerance (stated once): elementwise rtol = 1e-6 (north_star), with an absolute floor of
+1e-12 * max|Z| that only matters for moments that cancel to ~0.  Typical observed error is ~1e-15.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import rel_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from mtflearn_amd import _native
+    assert _native.device_count() > 0, "GPU tests need a HIP device"
+    return _native
+
+
+@pytest.fixture(scope="module")
+def zo():
+    from oracle import zernike_oracle
+    return zernike_oracle
+
+
+def _zps(n_max, size):
+    from mtflearn_amd import ZPs
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return ZPs(n_max, size)
+
+
+def _both_paths(native, z, array, mode):
+    """Moments from every kernel family the plan has for this input, keyed by name."""
+    plan = z._device_plan()
+    run = plan.transform_patches if mode == 0 else plan.transform_frame
+    out = {}
+    plan.set_path(native.PATH_GENERIC)
+    out["generic"] = run(array)
+    if plan.has_fast(mode, native.dtype_code(array.dtype)):
+        plan.set_path(native.PATH_FAST)
+        out["fast"] = run(array)
+    plan.set_path(native.PATH_AUTO)
+    return out
+
+
+# ------------------------------------------------------------------ golden vectors: batch path
+@pytest.mark.parametrize("key_in,key_out,n_max,size,expect_fast", [
+    ("blobs_32", "Z_blobs_8_32", 8, 32, True),
+    ("rand_f32_70_32", "Z_rand_f32_8_32", 8, 32, True),
+    ("rand_f32_70_32", "Z_rand_f32_10_32", 10, 32, True),
+    ("rand_f64_5_9", "Z_rand_f64_5_9", 5, 9, False),
+    ("rand_f32_6_11", "Z_rand_f32_10_11", 10, 11, False),
+    ("rand_f32_3_64", "Z_rand_f32_12_64", 12, 64, False),
+])
+def test_patches_golden(native, golden, key_in, key_out, n_max, size, expect_fast):
+    z = _zps(n_max, size)
+    res = _both_paths(native, z, np.ascontiguousarray(golden[key_in]), 0)
+    assert ("fast" in res) == expect_fast
+    for name, got in res.items():
+        assert got.dtype == np.float64 and got.shape == golden[key_out].shape
+        rel_close(got, golden[key_out])
+
+
+def test_patches_api_dtypes_and_layouts(golden):
+    z8 = _zps(8, 32)
+    zm = z8.transform(golden["blobs_32"])
+    assert type(zm).__name__ == "zmoments" and zm.patch_size == 32 and zm.valid_mask is None
+    np.testing.assert_array_equal(zm.n, golden["n_8"])
+    np.testing.assert_array_equal(zm.m, golden["m_8"])
+    np.testing.assert_allclose(zm.data[0, :5], [0.2939061752406, 0.01330401251592, 0.01135895180554,
+                                                0.00551359956386, -0.1162804839817], rtol=1e-10)
+    rel_close(zm.rot_maps([2, 3, 4, 6]), golden["pp2_rot_maps"], rtol=1e-9)
+    rel_close(zm.mirror_map(), golden["pp2_mirror"], rtol=1e-9)
+    # uint8 input (exact in float64), non-contiguous view, float64 copy of a float32 batch
+    rel_close(_zps(4, 8).transform(golden["rand_u8_3_8"]).data, golden["Z_rand_u8_4_8"])
+    p = golden["rand_f32_70_32"]
+    rel_close(z8.transform(p[::-1]).data, golden["Z_rand_f32_8_32"][::-1])
+    rel_close(z8.transform(p.astype(np.float64)).data, golden["Z_rand_f32_8_32"])
+    rel_close(z8.fit_transform(p).data, golden["Z_rand_f32_8_32"])
+
+
+# ------------------------------------------------------------------ golden vectors: dense path
+def test_frame_golden(native, golden, zo):
+    z8 = _zps(8, 32)
+    img32 = np.ascontiguousarray(golden["frame_f32_48_56"])
+    ref = golden["Zf_frame_f64cast_8_32"]
+    for arr in (img32, img32.astype(np.float64)):          # float32 values are exact in float64
+        res = _both_paths(native, z8, arr, 1)
+        assert "fast" in res
+        for got in res.values():
+            assert got.shape == ref.shape and got.dtype == np.float64
+            rel_close(got, ref)
+    # the reference's own float32-image output is only good to ~1e-7 * max|Z| (single-precision FFT)
+    zm = z8.transform(img32)
+    assert np.abs(zm.data - ref).max() <= 1e-6 * golden["Zf_frame_f32_8_32_maxabs"]
+    assert zm.valid_mask.shape == (48, 56) and zm.patch_size == 32
+    small = np.ascontiguousarray(golden["frame_f64_20_23"])
+    for key, (n_max, size) in {"Zf_small_5_9": (5, 9), "Zf_small_4_8": (4, 8), "Zf_small_10_11": (10, 11)}.items():
+        for got in _both_paths(native, _zps(n_max, size), small, 1).values():
+            rel_close(got, golden[key])
+
+
+def test_frame_tail_pipeline_golden(golden):
+    z = _zps(6, 12)
+    zm = z.transform(golden["frame_f32_24_28"])
+    rel_close(zm.data, golden["pp3_moments"])
+    np.testing.assert_array_equal(zm.valid_mask, golden["pp3_valid_mask"])
+    rel_close(zm.rot_maps([2, 3, 4, 6]), golden["pp3_rot_maps"], rtol=1e-8)
+    rel_close(zm.mirror_map(), golden["pp3_mirror"], rtol=1e-8)
+    rel_close(np.abs(zm.to_complex().data), np.abs(golden["pp3_complex"]), rtol=1e-8)
+
+
+# ------------------------------------------------------------------ oracle on seeded inputs, edge cases
+@pytest.mark.parametrize("n_patches", [1, 2, 63, 64, 65, 130, 257, 1000])
+def test_patches_ragged_counts(native, zo, n_patches):
+    rng = np.random.default_rng(n_patches)
+    z = _zps(8, 32)
+    p = rng.random((n_patches, 32, 32), dtype=np.float32) - 0.25
+    ref = zo.moments_patches(p, z.polynomials)
+    for got in _both_paths(native, z, p, 0).values():
+        rel_close(got, ref)
+
+
+@pytest.mark.parametrize("n_max,size,dtype", [
+    (8, 64, np.float32),      # RUN=4 batch kernel (64-B runs)
+    (10, 64, np.float32),
+    (4, 32, np.float32), (5, 32, np.float32), (6, 32, np.float32), (7, 32, np.float32), (9, 48, np.float32),
+    (8, 32, np.float64), (3, 16, np.float32), (6, 33, np.float32), (8, 72, np.float32), (0, 5, np.float64),
+    (12, 64, np.float64), (0, 1, np.float32),
+])
+def test_patches_shapes_vs_oracle(native, zo, n_max, size, dtype):
+    rng = np.random.default_rng(100 * n_max + size)
+    z = _zps(n_max, size)
+    p = (rng.random((77, size, size)) - 0.3).astype(dtype)
+    ref = zo.moments_patches(p, z.polynomials)
+    for got in _both_paths(native, z, p, 0).values():
+        rel_close(got, ref)
+
+
+@pytest.mark.parametrize("n_max,size,shape,dtype", [
+    (8, 32, (32, 32), np.float32),        # exactly one window fits
+    (8, 32, (33, 100), np.float32), (8, 32, (67, 129), np.float64),
+    (10, 32, (40, 70), np.float32), (12, 64, (70, 66), np.float32), (10, 72, (80, 90), np.float32),
+    (7, 33, (50, 41), np.float32), (5, 9, (9, 9), np.float64), (11, 24, (30, 200), np.float32),
+    (2, 3, (5, 7), np.float32), (0, 1, (3, 4), np.float64),
+])
+def test_frame_shapes_vs_oracle(native, zo, n_max, size, shape, dtype):
+    rng = np.random.default_rng(size * 1000 + shape[0])
+    z = _zps(n_max, size)
+    img = (rng.random(shape) - 0.5).astype(dtype)
+    ref = zo.moments_frame_direct(img, z.polynomials)
+    for got in _both_paths(native, z, img, 1).values():
+        rel_close(got, ref)
+
+
+def test_zero_and_constant_inputs(native):
+    z = _zps(8, 32)
+    assert not z.transform(np.zeros((5, 32, 32), np.float32)).data.any()
+    assert not z.transform(np.zeros((40, 50), np.float32)).data.any()
+    ones = z.transform(np.ones((3, 32, 32), np.float32)).data
+    ref = z.polynomials.reshape(45, -1).sum(axis=1) / (np.pi * 32 ** 2 / 4)
+    rel_close(ones, np.broadcast_to(ref, (3, 45)))
+
+
+def test_profile_counters(native):
+    z = _zps(8, 32)
+    plan = z._device_plan()
+    plan.profile(True)
+    for _ in range(3):
+        plan.transform_patches(np.ones((128, 32, 32), np.float32))
+    launches, ms = plan.profile_read()
+    plan.profile(False)
+    assert launches == 3 and ms > 0.0
+    assert plan.profile_read() == (0, 0.0)
+    assert plan.disk_pixels == 740
+
+
+def test_c_abi_argument_errors(native):
+    import ctypes
+    lib = native.load()
+    z = _zps(4, 8)
+    plan = z._device_plan()
+    buf = np.zeros((2, 8, 8), np.float32)
+    out = np.zeros((2, 15))
+    assert lib.zk_transform_patches(plan._h, buf.ctypes.data_as(ctypes.c_void_p), 7, 2,
+                                    out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == -10001
+    assert b"dtype" in lib.zk_last_error_string()
+    assert lib.zk_transform_patches(plan._h, None, 0, 2, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == -10001
+    assert lib.zk_transform_patches(plan._h, None, 0, 0, None) == 0              # empty batch is a no-op
+    handle = ctypes.c_void_p()
+    n = np.zeros(15, np.int32)
+    assert lib.zk_plan_create(8, 15, n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                              n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                              z.polynomials.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 99,
+                              ctypes.byref(handle)) == -10001                     # bad device index
+    with pytest.raises(RuntimeError, match="no fast"):
+        big = _zps(12, 64)._device_plan()
+        big.set_path(native.PATH_FAST)
+        big.transform_patches(np.zeros((2, 64, 64), np.float32))
+
+
+# ------------------------------------------------------------------ BASELINE sizes: properties on device
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_full_size_batch_equals_dense_and_linearity(native, zo):
+    """Config 2 (2048 x 2048 frame, 32-px, n_max=8): the batch kernel on all 4 068 289 sliding
+    windows and the dense kernel on the frame are independent kernels computing the same numbers at
+    the un-padded positions; both are linear in the image; 300 random positions match the oracle."""
+    torch = _torch()
+    from mtflearn_amd.synthetic import honeycomb_frame
+    from mtflearn_amd.distributed import patch_moments_device, frame_moments_device
+    K, H = 32, 2048
+    z = _zps(8, K)
+    plan = z._device_plan()
+    frame = honeycomb_frame(H, seed=0)
+    dev = torch.device("cuda:0")
+    f = torch.from_numpy(frame).to(dev)
+    win = f.unfold(0, K, 1).unfold(1, K, 1)                      # (H-K+1, H-K+1, K, K) view
+    nwin = H - K + 1
+    patches = win.reshape(-1, K, K).contiguous()                 # 16.7 GB
+    assert patches.shape[0] == nwin * nwin == 4068289
+    zp = patch_moments_device(plan, patches)                     # (N, 45)
+    zf = frame_moments_device(plan, f)                           # (45, H, W)
+    torch.cuda.synchronize()
+    ea = K - 1 - (K - 1) // 2
+    inner = zf[:, ea:ea + nwin, ea:ea + nwin].permute(1, 2, 0).reshape(-1, 45)
+    scale = zf.abs().max().item()
+    assert (zp - inner).abs().max().item() <= 1e-12 * scale
+    # oracle spot check
+    rng = np.random.default_rng(5)
+    rows, cols = rng.integers(0, H, 300), rng.integers(0, H, 300)
+    ref = np.stack([zo.moments_frame_direct(frame, z.polynomials, rows=[r], cols=[c])[:, 0, 0]
+                    for r, c in zip(rows, cols)])
+    got = zf[:, torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev)].T.cpu().numpy()
+    rel_close(got, ref)
+    # linearity of both kernels: Z(2 f + 3 g) = 2 Z(f) + 3 Z(g); float32 inputs chosen so the
+    # combination is exact (small integers / 256)
+    g1 = torch.randint(0, 64, (H, H), device=dev).float() / 256
+    g2 = torch.randint(0, 64, (H, H), device=dev).float() / 256
+    lhs = frame_moments_device(plan, 2 * g1 + 3 * g2)
+    rhs = 2 * frame_moments_device(plan, g1) + 3 * frame_moments_device(plan, g2)
+    assert (lhs - rhs).abs().max().item() <= 1e-12 * lhs.abs().max().item()
+    del lhs, rhs, zf, inner
+    p1 = torch.randint(0, 64, (100000, K, K), device=dev).float() / 256
+    p2 = torch.randint(0, 64, (100000, K, K), device=dev).float() / 256
+    lhs = patch_moments_device(plan, 2 * p1 + 3 * p2)
+    rhs = 2 * patch_moments_device(plan, p1) + 3 * patch_moments_device(plan, p2)
+    assert (lhs - rhs).abs().max().item() <= 1e-12 * lhs.abs().max().item()
+
+
+def test_row_bands_reassemble_full_frame(native):
+    """The multi-GPU row-band entry point: bands computed separately equal the full result."""
+    torch = _torch()
+    from mtflearn_amd.distributed import frame_moments_device, shard_bounds
+    z = _zps(10, 32)
+    plan = z._device_plan()
+    dev = torch.device("cuda:0")
+    img = torch.rand((203, 301), device=dev)
+    full = frame_moments_device(plan, img)
+    for world in (2, 3, 8):
+        parts = []
+        for rank in range(world):
+            start, count, padded = shard_bounds(203, rank, world)
+            parts.append(frame_moments_device(plan, img, row0=start, n_rows=count))
+        assert torch.equal(torch.cat(parts, dim=1), full)
+
+
+def test_config3_and_config5_sizes(native, zo):
+    """Config 3 (64-px, n_max=12) and config 5 (n_max=10) at 4096 x 4096 would write 12.2 / 8.9 GB;
+    here a 1024-row band of the 4096-wide frame exercises the same kernels and grid shapes, checked
+    at random positions against the oracle."""
+    torch = _torch()
+    from mtflearn_amd.synthetic import honeycomb_frame
+    from mtflearn_amd.distributed import frame_moments_device
+    frame = honeycomb_frame(4096, seed=1)
+    dev = torch.device("cuda:0")
+    f = torch.from_numpy(frame).to(dev)
+    rng = np.random.default_rng(9)
+    for n_max, size in ((12, 64), (10, 32)):
+        z = _zps(n_max, size)
+        band = frame_moments_device(z._device_plan(), f, row0=1536, n_rows=1024)
+        rows, cols = rng.integers(1536, 2560, 40), rng.integers(0, 4096, 40)
+        ref = np.stack([zo.moments_frame_direct(frame, z.polynomials, rows=[r], cols=[c])[:, 0, 0]
+                        for r, c in zip(rows, cols)])
+        got = band[:, torch.from_numpy(rows - 1536).to(dev), torch.from_numpy(cols).to(dev)].T.cpu().numpy()
+        rel_close(got, ref)
+        del band

@@ -1,0 +1,128 @@
+"""The CPU oracle (oracle/) is pinned against the vectors captured from the reference and against
+the reference's own known-answer tests (reference tests/features/test_zmoments.py:5-88)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_close
+from oracle import zernike_oracle as zo
+
+
+def test_basis_bit_identical(golden):
+    for key, (n_max, size) in {"basis_8_32": (8, 32), "basis_5_9": (5, 9), "basis_10_11": (10, 11),
+                               "basis_4_8": (4, 8)}.items():
+        n, m, v = zo.zernike_basis(n_max, size)
+        assert np.array_equal(v, golden[key]), key
+    n, m, v = zo.zernike_basis(8, 32)
+    assert np.array_equal(n, golden["n_8"]) and np.array_equal(m, golden["m_8"])
+    assert v[4, 16, 20] == -1.436466694726738                      # SURVEY 8a anchor
+    assert zo.unit_disk_area(32) == pytest.approx(804.247719318987, rel=1e-15)
+    _, _, v64 = zo.zernike_basis(12, 64)
+    assert np.array_equal(v64[:, ::7, ::5], golden["basis_12_64_sample"])
+    assert np.count_nonzero(v[0]) == 740 and np.count_nonzero(v64[0]) == 3096
+
+
+def test_patches_match_reference(golden):
+    _, _, b8 = zo.zernike_basis(8, 32)
+    z = zo.moments_patches(golden["blobs_32"], b8)
+    rel_close(z, golden["Z_blobs_8_32"], rtol=1e-12)
+    np.testing.assert_allclose(z[0, :5], [0.2939061752406, 0.01330401251592, 0.01135895180554,
+                                          0.00551359956386, -0.1162804839817], rtol=1e-11)
+    rel_close(zo.moments_patches(golden["rand_f32_70_32"], b8), golden["Z_rand_f32_8_32"], rtol=1e-12)
+    _, _, b59 = zo.zernike_basis(5, 9)
+    rel_close(zo.moments_patches(golden["rand_f64_5_9"], b59), golden["Z_rand_f64_5_9"], rtol=1e-12)
+    _, _, b48 = zo.zernike_basis(4, 8)
+    rel_close(zo.moments_patches(golden["rand_u8_3_8"], b48), golden["Z_rand_u8_4_8"], rtol=1e-12)
+
+
+def test_frame_fft_and_direct_match_reference(golden):
+    n, _, b8 = zo.zernike_basis(8, 32)
+    img = golden["frame_f32_48_56"].astype(np.float64)
+    ref = golden["Zf_frame_f64cast_8_32"]
+    rel_close(zo.moments_frame_fft(img, b8, n), ref, rtol=1e-9, atol_scale=1e-13)
+    rel_close(zo.moments_frame_direct(img, b8), ref, rtol=1e-9, atol_scale=1e-13)
+    for key, (n_max, size) in {"Zf_small_5_9": (5, 9), "Zf_small_4_8": (4, 8), "Zf_small_10_11": (10, 11)}.items():
+        nn, _, b = zo.zernike_basis(n_max, size)
+        rel_close(zo.moments_frame_direct(golden["frame_f64_20_23"], b), golden[key], rtol=1e-9,
+                  atol_scale=1e-13)
+        rel_close(zo.moments_frame_fft(golden["frame_f64_20_23"], b, nn), golden[key], rtol=1e-9,
+                  atol_scale=1e-13)
+
+
+def test_c_restatement_matches(golden):
+    lib_path = os.path.join(ROOT, "oracle", "_build", "libzernike_oracle.so")
+    if not os.path.exists(lib_path):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(lib_path)
+    _, _, b8 = zo.zernike_basis(8, 32)
+    p = np.ascontiguousarray(golden["rand_f32_70_32"][:9])
+    out = np.empty((9, 45))
+    lib.zko_patches(p.ctypes.data_as(ctypes.c_void_p), 0, ctypes.c_int64(9), 32, 45,
+                    b8.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    rel_close(out, golden["Z_rand_f32_8_32"][:9], rtol=1e-10)
+    _, _, b59 = zo.zernike_basis(5, 9)
+    img = np.ascontiguousarray(golden["frame_f64_20_23"])
+    outf = np.empty((21, 20, 23))
+    lib.zko_frame(img.ctypes.data_as(ctypes.c_void_p), 1, ctypes.c_int64(20), ctypes.c_int64(23), 9, 21,
+                  b59.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(0), ctypes.c_int64(20),
+                  outf.ctypes.data_as(ctypes.c_void_p))
+    rel_close(outf, golden["Zf_small_5_9"], rtol=1e-9, atol_scale=1e-13)
+
+
+def test_postprocessing_matches_reference(golden):
+    n, m, b8 = zo.zernike_basis(8, 32)
+    z = golden["Z_blobs_8_32"]
+    zc, nc, mc = zo.to_complex(z, n, m)
+    np.testing.assert_array_equal(zc, golden["pp2_complex"])
+    np.testing.assert_array_equal(nc, golden["pp2_complex_n"])
+    np.testing.assert_array_equal(mc, golden["pp2_complex_m"])
+    np.testing.assert_allclose(zo.rot_maps(z, n, m, [2, 3, 4, 6]), golden["pp2_rot_maps"], rtol=1e-13)
+    np.testing.assert_allclose(golden["pp2_rot_maps"][0],
+                               [-0.800721433518, 0.948956683138, -0.313956509108, -0.11684582421], rtol=1e-10)
+    np.testing.assert_allclose(zo.rot_maps(z, n, m, [3, 6], p=None), golden["pp2_rot_maps_pnone"], rtol=1e-13)
+    np.testing.assert_allclose(zo.rot_maps(z, n, m, [3], m_unselect=(0, 1, 2)),
+                               golden["pp2_rot_maps_unsel012"], rtol=1e-13)
+    with pytest.raises(ValueError, match="m=0 must be included"):
+        zo.rot_maps(z, n, m, [3], m_unselect=(1,))
+    np.testing.assert_allclose(zo.mirror_map(z, n, m), golden["pp2_mirror"], rtol=1e-13)
+    assert golden["pp2_mirror"][0] == pytest.approx(0.9935520868527856, rel=1e-12)
+    np.testing.assert_allclose(zo.normalize(z, 2), golden["pp2_norm2"], rtol=1e-15)
+    np.testing.assert_allclose(zo.normalize(z), golden["pp2_norm_none"], rtol=1e-15)
+    np.testing.assert_allclose(zo.rotate(z, n, m, 30.0)[0], golden["pp2_rotate30"], rtol=1e-14)
+    zr, nr, mr = zo.to_real(zc, nc, mc)
+    np.testing.assert_array_equal(zr, golden["pp2_toreal"])
+    np.testing.assert_array_equal(nr, golden["pp2_toreal_n"])
+    np.testing.assert_array_equal(mr, golden["pp2_toreal_m"])
+    d, ns, ms = zo.select(z, n, m, [1, -2])
+    np.testing.assert_array_equal(d, golden["pp2_select"])
+    np.testing.assert_array_equal(ms, golden["pp2_select_m"])
+    assert np.array_equal(zo.unselect(z, n, m, [0, 1])[2], golden["pp2_unselect_m"])
+    # rank-3
+    n6, m6, _ = zo.zernike_basis(6, 12)
+    f = golden["pp3_moments"]
+    np.testing.assert_array_equal(zo.to_complex(f, n6, m6)[0], golden["pp3_complex"])
+    np.testing.assert_allclose(zo.rot_maps(f, n6, m6, [2, 3, 4, 6]), golden["pp3_rot_maps"], rtol=1e-12)
+    np.testing.assert_allclose(zo.mirror_map(f, n6, m6), golden["pp3_mirror"], rtol=1e-12)
+    np.testing.assert_allclose(zo.rotate(f, n6, m6, 45.0)[0], golden["pp3_rotate45"], rtol=1e-14)
+    np.testing.assert_array_equal(zo.valid_mask((24, 28), 12), golden["pp3_valid_mask"])
+    np.testing.assert_array_equal(zo.valid_mask((20, 23), 9), golden["valid_mask_9_20_23"])
+
+
+def test_index_algebra_matches_reference(golden):
+    n, m = golden["n_8"], golden["m_8"]
+    np.testing.assert_array_equal(zo.complex_matrix(n, m), golden["cmat_8"])
+    inv, nr, mr = zo.real_matrix(golden["pp2_complex_n"], golden["pp2_complex_m"])
+    np.testing.assert_array_equal(inv, golden["rmat_8"])
+    np.testing.assert_array_equal(nr, golden["rmat_8_n"])
+    np.testing.assert_array_equal(mr, golden["rmat_8_m"])
+    np.testing.assert_array_equal(zo.rot_maps_matrix([1, 2, 3, 4, 6], m), golden["rotmat_8"])
+    np.testing.assert_array_equal(zo.nm2j(n, m), golden["nm2j_8"])
+    np.testing.assert_array_equal(zo.nm2j(n, m), np.arange(45))
+    np.testing.assert_array_equal(zo.nm2j_complex(golden["pp2_complex_n"], golden["pp2_complex_m"]),
+                                  golden["nm2j_complex_8"])
+    # known answers of reference tests/features/test_zmoments.py:5-21
+    assert [zo.nm2j(*p) for p in [(0, 0), (1, -1), (2, 0), (3, 1), (4, -4), (5, 3)]] == [0, 1, 4, 8, 10, 19]
+    np.testing.assert_array_equal(zo.nm2j([0, 1, 2, 2, 3], [0, -1, 0, 2, 3]), [0, 1, 4, 5, 9])
