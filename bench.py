@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- Zernike-moment hot path on MI355X (contract: see the task brief / DESIGN.md section 7).
+
+A "step" is one pass of the batch-of-patches hot path (``ZPs.transform`` on a 3-D batch, reference
+``mtflearn/features/_zps.py:146-157``) over every dense 32-px sliding window of one synthetic
+2048 x 2048 STEM-like frame per GPU (BASELINE.json configs[1]: 4 068 289 patches, n_max = 8),
+float32 patches resident in HBM, float64 moments out.  With N > 1 ranks every rank owns its own
+frame (weak scaling) and, unless ``--no-allgather`` is given, each step ends with the single
+RCCL all-gather that reassembles the (N_total, 45) moment matrix on every rank, pipelined
+against the next step's kernel on RCCL's own stream.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      -- the batch kernel: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak
+  cpu_baseline  -- the oracle's restatement of the reference CPU path (same NumPy call) on this host
+  dense_frame   -- the dense-frame kernel (reference _zps.py:159-193) on the same frame, for context
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "motif-learn_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TF = 78.6     # public datasheet figure (not in the local guide); 62 TF measured,
+                               # tools/micro_sfma.hip, profiles/r01_micro_sfma.txt
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frame", type=int, default=2048, help="frame side (configs[1]: 2048)")
+    ap.add_argument("--size", type=int, default=32)
+    ap.add_argument("--n-max", type=int, default=8)
+    ap.add_argument("--no-allgather", action="store_true", help="N>1: time the kernels only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-frame side measurement")
+    return ap.parse_args()
+
+
+def cpu_baseline(z, frame, size):
+    """Reference CPU path (np.dot of the flattened batch with the float64 basis, _zps.py:151-155)
+    restated by the oracle, timed on a bounded sample of the same workload: the first 400k sliding
+    windows of the frame, repeated until ~10 s have elapsed."""
+    from oracle import zernike_oracle as zo
+    from mtflearn_amd.synthetic import sliding_patches
+    n_side = frame.shape[0] - size + 1
+    rows = max(1, min(n_side, 400000 // n_side))
+    sample = sliding_patches(frame, size, rows=range(rows))
+    zo.moments_patches(sample[:1000], z.polynomials)                    # warm BLAS
+    done, t0 = 0, time.perf_counter()
+    while True:
+        zo.moments_patches(sample, z.polynomials)
+        done += sample.shape[0]
+        dt = time.perf_counter() - t0
+        if dt > 10.0:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": done / dt, "unit": "patches/s", "cores": int(threads), "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"oracle moments_patches (np.dot, reference _zps.py:151-155) on the first "
+                      f"{sample.shape[0]} sliding {size}-px float32 windows of the frame, "
+                      f"{done // sample.shape[0]} passes in {dt:.1f} s"}
+
+
+def cpu_dense_baseline(z, frame):
+    """The reference's dense path (fftconvolve, _zps.py:159-193) on a 512 x 512 crop."""
+    from oracle import zernike_oracle as zo
+    crop = np.ascontiguousarray(frame[:512, :512])
+    t0 = time.perf_counter()
+    zo.moments_frame_fft(crop, z.polynomials, z.n)
+    dt = time.perf_counter() - t0
+    return {"value": crop.size / dt, "unit": "patches/s", "cores": 1, "kind": "port",
+            "sample": f"oracle moments_frame_fft (scipy fftconvolve, single-threaded) on a 512x512 crop, {dt:.2f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ["MTFLEARN_AMD_DEVICE"] = str(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mtflearn_amd import ZPs, _native
+    from mtflearn_amd.synthetic import honeycomb_frame
+    from mtflearn_amd.distributed import patch_moments_device, frame_moments_device
+
+    K, H = args.size, args.frame
+    z = ZPs(n_max=args.n_max, size=K)
+    plan = z._device_plan()
+    n_poly = len(z.n)
+    frame = honeycomb_frame(H, seed=rank)                               # one frame per rank (weak scaling)
+    f_dev = torch.from_numpy(frame).to(dev)
+    patches = f_dev.unfold(0, K, 1).unfold(1, K, 1).reshape(-1, K, K).contiguous()
+    n_local = patches.shape[0]
+    gather = world > 1 and not args.no_allgather
+    outs = [torch.empty((n_local, n_poly), dtype=torch.float64, device=dev) for _ in range(2 if gather else 1)]
+    fulls = [torch.empty((world * n_local, n_poly), dtype=torch.float64, device=dev) for _ in range(2)] if gather else []
+    fast = plan.has_path(0, _native.ZK_F32, _native.PATH_SEPARABLE)
+
+    pending = [None, None]
+
+    def step(i):
+        b = i & 1 if gather else 0
+        if gather and pending[b] is not None:
+            pending[b].wait()                                            # buffer pair b is free again
+        patch_moments_device(plan, patches, out=outs[b])
+        if gather:
+            pending[b] = dist.all_gather_into_tensor(fulls[b], outs[b], async_op=True)
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    fence()
+    plan.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    drain()
+    fence()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = plan.profile_read()
+    plan.profile(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+
+    # ---- all-gather alone (reported beside the pipelined number) ---------------------------------
+    allgather_ms = None
+    if gather:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            dist.all_gather_into_tensor(fulls[0], outs[0])
+        fence()
+        allgather_ms = (time.perf_counter() - t1) / 3 * 1e3
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n_local / (elapsed / args.steps)
+    kern_ms = kernel_ms / max(launches, 1)
+    alg_bytes = n_local * (K * K * 4 + 8 * n_poly)                       # K^2 s_in + 8 N_poly per patch
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath)).get(f"patches_{K}_{args.n_max}_{H}")
+            traffic = rec and rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    result = {
+        "metric": "patches/s (32x32, n_max=8) + achieved HBM GB/s vs roofline",
+        "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"configs[1]: synthetic {H}x{H} honeycomb STEM frame per GPU, all {n_local} dense "
+                               f"{K}-px sliding windows as a float32 (N,{K},{K}) batch resident in HBM, n_max={args.n_max} "
+                               f"({n_poly} moments), float64 out",
+                   "patches_per_gpu": n_local, "patch_size": K, "n_max": args.n_max, "input_dtype": "f32",
+                   "kernel": "zk_patch_sep_kernel (mirror-folded, row-separable, LDS-DMA staged)" if fast else "zk_generic_kernel",
+                   "allgather_in_step": bool(gather), "parallelism": f"dp{world} (patch blocks, one all-gather)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel_ms": kern_ms, "launches": launches,
+                     "algorithmic_bytes_per_patch": K * K * 4 + 8 * n_poly},
+        "kernel_only_patches_per_s": world * n_local / (kern_ms * 1e-3),
+    }
+    if allgather_ms is not None:
+        result["allgather"] = {"ms_alone": allgather_ms, "bytes_per_rank_out": n_local * n_poly * 8,
+                               "gathered_bytes": world * n_local * n_poly * 8}
+
+    # ---- dense-frame kernels on the same frame (side measurement, not `value`) -----------------------
+    if not args.no_dense:
+        out_f = frame_moments_device(plan, f_dev)
+        torch.cuda.synchronize()
+        npx, disk = H * H, plan.disk_pixels
+        dense = {"positions": npx, "bound": "fp64-valu", "kernels": {}}
+        for path in (_native.PATH_SEPARABLE, _native.PATH_FOLDED):
+            if not plan.has_path(1, _native.ZK_F32, path):
+                continue
+            plan.set_path(path)
+            frame_moments_device(plan, f_dev, out=out_f)
+            torch.cuda.synchronize()
+            plan.profile(True)
+            for _ in range(5):
+                frame_moments_device(plan, f_dev, out=out_f)
+            torch.cuda.synchronize()
+            ln, ms = plan.profile_read()
+            plan.profile(False)
+            fms = ms / ln
+            dense["kernels"][_native.PATH_NAMES[path]] = {
+                "patches_per_s": npx / (fms * 1e-3), "kernel_ms": fms,
+                "hbm_GBps_algorithmic": npx * (4 + 8 * n_poly) / (fms * 1e-3) / 1e9,
+                "hbm_frac": npx * (4 + 8 * n_poly) / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "fp64_TFLOPs_direct_equiv": npx * 2.0 * disk * n_poly / (fms * 1e-3) / 1e12}
+        plan.set_path(_native.PATH_AUTO)
+        result["dense_frame"] = dense
+        del out_f
+
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(z, frame, K)
+        result["cpu_baseline_dense"] = cpu_dense_baseline(z, frame)
+        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+    print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

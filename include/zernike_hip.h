@@ -42,10 +42,11 @@ extern "C" {
 #define ZK_E_NODEVICE (-10002)
 #define ZK_E_NOMEM    (-10003)
 
-/* kernel selection, for tests and A/B measurements (default ZK_PATH_AUTO) */
-#define ZK_PATH_AUTO    0
-#define ZK_PATH_GENERIC 1   /* any size / n_max, unfolded direct summation            */
-#define ZK_PATH_FAST    2   /* parity-folded, LDS-staged; fails if the plan has none   */
+/* kernel selection, for tests and A/B measurements (default ZK_PATH_AUTO = best available) */
+#define ZK_PATH_AUTO      0
+#define ZK_PATH_GENERIC   1  /* any size / n_max / dtype: unfolded direct summation, ~1e-16 of the definition */
+#define ZK_PATH_FOLDED    2  /* frame only: mirror-folded direct summation (4x fewer FMAs), ~1e-15            */
+#define ZK_PATH_SEPARABLE 3  /* mirror-folded row-separable sums (Legendre products), ~1e-13; fastest       */
 
 typedef struct zk_plan zk_plan;
 
@@ -60,25 +61,28 @@ const char* zk_last_error_string(void);
  *   n, m  : host, (n_poly) int32 radial order / azimuthal frequency per basis function, in
  *           the order of `basis`                                                  (_zps.py:74-81)
  * The plan uploads the disk-masked basis, pre-divided by the reference's normalising area
- * pi*size^2/4 (_zps.py:154,177), and when the basis has the x/y mirror parities of real
- * Zernike functions also a 4-quadrant parity-folded table used by the fast kernels.
+ * pi*size^2/4 (_zps.py:154,177).  When (n, m, basis) is the reference's full real Zernike set
+ * it also builds the mirror-folded table and the row-separable (Legendre) tables of the fast
+ * kernels, after verifying that they reproduce `basis` at every pixel of the disk.
  */
 int  zk_plan_create(int size, int n_poly, const int32_t* n, const int32_t* m,
                     const double* basis, int device, zk_plan** out);
 void zk_plan_destroy(zk_plan* plan);
 
-/* Introspection: 1 if the plan holds the parity-folded tables / a fast kernel for `dtype`. */
-int zk_plan_has_fast(const zk_plan* plan, int mode /*0 patches, 1 frame*/, int dtype);
+/* Introspection: 1 if `path` (ZK_PATH_*) is available for `mode` (0 patches, 1 frame) and `dtype`. */
+int zk_plan_has_path(const zk_plan* plan, int mode, int dtype, int path);
 /* Number of pixels inside the unit disk (rho <= 1 as evaluated by the caller's basis). */
 int zk_plan_disk_pixels(const zk_plan* plan);
-/* Force a kernel family (ZK_PATH_*). */
+/* Force a kernel family (ZK_PATH_*); a forced path that is unavailable makes transforms fail. */
 int zk_plan_set_path(zk_plan* plan, int path);
 
 /*
  * Batch of patches (reference _zps.py:146-157):
  *   out[p, j] = sum_{r,c} patches[p, r, c] * basis[j, r, c] / (pi size^2 / 4)
  *   patches : (N, size, size) of `dtype`, C order;  out : (N, n_poly) float64.
- * Host variant copies in/out through staging buffers owned by the plan.
+ * Host variant copies in/out through staging buffers owned by the plan, on the plan's stream,
+ * and returns when the result is in out_host.  The *_dev variants enqueue the kernel on exactly
+ * `hip_stream` (a hipStream_t; NULL = HIP's default stream) and return without synchronising.
  */
 int zk_transform_patches(zk_plan* plan, const void* patches_host, int dtype, int64_t n_patches,
                          double* out_host);

@@ -118,6 +118,7 @@ extern "C" void zk_plan_destroy(zk_plan* p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   zk_fold_free(p);
+  zk_sep_free(p);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   if (p->d_pix) (void)hipFree(p->d_pix);
   if (p->d_gen_tab) (void)hipFree(p->d_gen_tab);
@@ -154,6 +155,7 @@ extern "C" int zk_plan_create(int size, int n_poly, const int32_t* n, const int3
   }
   if (!rc) rc = build_generic_tables(p, basis);
   if (!rc) rc = zk_fold_build(p, basis);
+  if (!rc) rc = zk_sep_build(p, basis);
   if (rc) {
     std::string keep = g_last_error;
     zk_plan_destroy(p);
@@ -164,15 +166,32 @@ extern "C" int zk_plan_create(int size, int n_poly, const int32_t* n, const int3
   return 0;
 }
 
-extern "C" int zk_plan_has_fast(const zk_plan* p, int mode, int dtype) {
-  if (!p) return 0;
-  return mode == 0 ? (int)zk_fast_patches_available(p, dtype) : (int)zk_fast_frame_available(p, dtype);
+static bool path_available(const zk_plan* p, int mode, int dtype, int path) {
+  switch (path) {
+    case ZK_PATH_GENERIC: return true;
+    case ZK_PATH_FOLDED: return mode == 1 && zk_fast_frame_available(p, dtype);
+    case ZK_PATH_SEPARABLE: return mode == 0 ? zk_sep_patches_available(p, dtype) : zk_sep_frame_available(p, dtype);
+  }
+  return false;
+}
+
+// ZK_PATH_AUTO: separable, else folded (frame), else generic
+static int resolve_path(const zk_plan* p, int mode, int dtype) {
+  if (p->path != ZK_PATH_AUTO) return path_available(p, mode, dtype, p->path) ? p->path : -1;
+  if (path_available(p, mode, dtype, ZK_PATH_SEPARABLE)) return ZK_PATH_SEPARABLE;
+  if (path_available(p, mode, dtype, ZK_PATH_FOLDED)) return ZK_PATH_FOLDED;
+  return ZK_PATH_GENERIC;
+}
+
+extern "C" int zk_plan_has_path(const zk_plan* p, int mode, int dtype, int path) {
+  if (!p || (dtype != ZK_F32 && dtype != ZK_F64)) return 0;
+  return (int)path_available(p, mode, dtype, path);
 }
 
 extern "C" int zk_plan_disk_pixels(const zk_plan* p) { return p ? p->npx : 0; }
 
 extern "C" int zk_plan_set_path(zk_plan* p, int path) {
-  if (!p || path < ZK_PATH_AUTO || path > ZK_PATH_FAST) return zk_fail(ZK_E_BADARG, "bad path");
+  if (!p || path < ZK_PATH_AUTO || path > ZK_PATH_SEPARABLE) return zk_fail(ZK_E_BADARG, "bad path");
   p->path = path;
   return 0;
 }
@@ -196,10 +215,10 @@ extern "C" int zk_transform_patches_dev(zk_plan* p, const void* patches, int dty
   if (n_patches == 0) return 0;
   if (!patches || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
   ZK_HIP(hipSetDevice(p->device));
-  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : p->stream;
-  const bool fast = zk_fast_patches_available(p, dtype);
-  if (p->path == ZK_PATH_FAST && !fast) return zk_fail(ZK_E_BADARG, "plan has no fast patch kernel for this shape");
-  if (fast && p->path != ZK_PATH_GENERIC) return zk_launch_fast_patches(p, patches, dtype, n_patches, out, s);
+  hipStream_t s = (hipStream_t)hip_stream;  // exactly the caller's stream; NULL is HIP's default stream
+  const int path = resolve_path(p, 0, dtype);
+  if (path < 0) return zk_fail(ZK_E_BADARG, "the forced kernel path is not available for this plan / dtype");
+  if (path == ZK_PATH_SEPARABLE) return zk_launch_sep_patches(p, patches, dtype, n_patches, out, s);
   return zk_launch_generic_patches(p, patches, dtype, n_patches, out, s);
 }
 
@@ -213,10 +232,11 @@ extern "C" int zk_transform_frame_dev(zk_plan* p, const void* image, int dtype, 
   if (n_rows == 0) return 0;
   if (!image || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
   ZK_HIP(hipSetDevice(p->device));
-  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : p->stream;
-  const bool fast = zk_fast_frame_available(p, dtype);
-  if (p->path == ZK_PATH_FAST && !fast) return zk_fail(ZK_E_BADARG, "plan has no fast frame kernel for this shape");
-  if (fast && p->path != ZK_PATH_GENERIC) return zk_launch_fast_frame(p, image, dtype, H, W, row0, n_rows, out, s);
+  hipStream_t s = (hipStream_t)hip_stream;  // exactly the caller's stream; NULL is HIP's default stream
+  const int path = resolve_path(p, 1, dtype);
+  if (path < 0) return zk_fail(ZK_E_BADARG, "the forced kernel path is not available for this plan / dtype");
+  if (path == ZK_PATH_SEPARABLE) return zk_launch_sep_frame(p, image, dtype, H, W, row0, n_rows, out, s);
+  if (path == ZK_PATH_FOLDED) return zk_launch_fast_frame(p, image, dtype, H, W, row0, n_rows, out, s);
   return zk_launch_generic_frame(p, image, dtype, H, W, row0, n_rows, out, s);
 }
 

@@ -1,5 +1,5 @@
 // zk_fold.h -- parity-folded Zernike tables and the device-side accumulation step shared by
-// the fast kernels (zk_fast_frame.hip, zk_fast_patches.hip).
+// the direct folded frame kernel (zk_fast_frame.hip) and, for the folds, by zk_sep.h.
 //
 // Every real Zernike function on the symmetric grid linspace(-1,1,K)^2 (reference
 // _zps.py:68-72) is even or odd under the column mirror c -> K-1-c and under the row mirror
@@ -39,14 +39,6 @@ inline int zk_class_of(int m) {
   return m >= 0 ? ((am & 1) ? ZK_OE : ZK_EE) : ((am & 1) ? ZK_EO : ZK_OO);
 }
 
-// One unit of the batch kernel: 16 folded pixels of one row pair, as 4 folded granules.
-struct zk_unit {
-  int32_t run_off[4];  // byte offsets inside a patch of the source runs (RUN=8 uses [0],[1])
-  int32_t mask;        // bit q set: folded granule q has a pixel inside the disk
-  int32_t tab_first;   // index of the unit's first active granule in the granule table
-  int32_t pad[2];
-};
-
 struct zk_fold_tables {
   int kernel_nmax = -1;     // instantiated NMAX the tables are padded to (>= the plan's n_max)
   int np_kernel = 0;        // zk_set<kernel_nmax>::NP
@@ -58,11 +50,6 @@ struct zk_fold_tables {
   int4* d_fpx_off = nullptr;    // [n_fpx] tile element offsets of a, b, c, d
   double* d_ftab = nullptr;     // [n_fpx][np_kernel], class order, scaled by weight/area
 
-  // batch kernel (float32 patches, K % 16 == 0, K >= 32)
-  int run = 0;              // granules per source run: 8 (K == 32) or 4
-  int n_units = 0;
-  zk_unit* d_units = nullptr;   // [n_units]
-  double* d_ptab = nullptr;     // [active granules][4][np_kernel]
 };
 
 #ifdef __HIPCC__

@@ -5,7 +5,7 @@
 
 #include "zk_fold.h"
 
-// NMAX values the fast kernels are instantiated for (zk_fast_frame.hip / zk_fast_patches.hip);
+// NMAX values the folded frame kernel is instantiated for (zk_fast_frame.hip);
 // a plan with n_max below an entry is zero-padded up to it.
 static const int kKernelNmax[] = {4, 6, 8, 10, 12};
 
@@ -15,7 +15,7 @@ static int pick_kernel_nmax(int n_max) {
   return -1;
 }
 
-static int full_set_nmax(const zk_plan* p) {
+int zk_full_set_nmax(const zk_plan* p) {
   // the plan's (n, m) must be the complete real set 0..n_max in reference order (_zps.py:77-81)
   int n_max = -1;
   for (int k = 0; k <= 64; ++k)
@@ -42,15 +42,13 @@ void zk_fold_free(zk_plan* p) {
   if (f->d_colmap) (void)hipFree(f->d_colmap);
   if (f->d_fpx_off) (void)hipFree(f->d_fpx_off);
   if (f->d_ftab) (void)hipFree(f->d_ftab);
-  if (f->d_units) (void)hipFree(f->d_units);
-  if (f->d_ptab) (void)hipFree(f->d_ptab);
   delete f;
   p->fold = nullptr;
 }
 
 int zk_fold_build(zk_plan* p, const double* basis) {
   const int K = p->size, NP = p->n_poly;
-  const int n_max = full_set_nmax(p);
+  const int n_max = zk_full_set_nmax(p);
   if (n_max < 0) return 0;  // not a standard set: generic kernels only
   const int knm = pick_kernel_nmax(n_max);
   if (knm < 0) return 0;
@@ -122,42 +120,5 @@ int zk_fold_build(zk_plan* p, const double* basis) {
   if ((rc = upload(&f->d_fpx_off, off))) return rc;
   if ((rc = upload(&f->d_ftab, ftab))) return rc;
 
-  // ---- batch kernel (float32 patches) -------------------------------------------------
-  if (K % 16 == 0 && K >= 32) {
-    f->run = (K == 32) ? 8 : 4;
-    std::vector<zk_unit> units;
-    std::vector<double> ptab;
-    int granules = 0;
-    for (int r = 0; r < K / 2; ++r)
-      for (int c0 = 0; c0 + 16 <= K / 2; c0 += 16) {
-        zk_unit u = {};
-        const int rm = K - 1 - r;
-        if (f->run == 8) {
-          u.run_off[0] = r * K * 4;
-          u.run_off[1] = rm * K * 4;
-        } else {
-          u.run_off[0] = (r * K + c0) * 4;
-          u.run_off[1] = (r * K + K - 16 - c0) * 4;
-          u.run_off[2] = (rm * K + c0) * 4;
-          u.run_off[3] = (rm * K + K - 16 - c0) * 4;
-        }
-        u.tab_first = granules;
-        for (int q = 0; q < 4; ++q) {
-          bool act = false;
-          for (int e = 0; e < 4; ++e) act = act || qact[(size_t)r * Q + c0 + 4 * q + e];
-          if (!act) continue;
-          u.mask |= 1 << q;
-          for (int e = 0; e < 4; ++e) {
-            const double* src = &qtab[((size_t)r * Q + c0 + 4 * q + e) * npk];
-            ptab.insert(ptab.end(), src, src + npk);
-          }
-          ++granules;
-        }
-        if (u.mask) units.push_back(u);
-      }
-    f->n_units = (int)units.size();
-    if ((rc = upload(&f->d_units, units))) return rc;
-    if ((rc = upload(&f->d_ptab, ptab))) return rc;
-  }
   return 0;
 }

@@ -16,6 +16,7 @@
 enum zk_class { ZK_EE = 0, ZK_OE = 1, ZK_EO = 2, ZK_OO = 3 };  // <x parity><y parity>, E even / O odd
 
 struct zk_fold_tables;  // zk_fold.h
+struct zk_sep_tables;   // zk_sep.h
 
 struct zk_plan {
   int size = 0;
@@ -32,6 +33,9 @@ struct zk_plan {
 
   // ---- parity-folded tables (fast kernels) ----------------------------------------
   zk_fold_tables* fold = nullptr;  // nullptr when the basis lacks the mirror parities
+
+  // ---- row-separable tables (fastest kernels) ----------------------------------------
+  zk_sep_tables* sep = nullptr;    // nullptr when the basis is not the standard polynomial set
 
   // ---- execution state -------------------------------------------------------------
   hipStream_t stream = nullptr;  // owned; host-variant calls and default for *_dev
@@ -66,12 +70,20 @@ int zk_launch_generic_patches(zk_plan* p, const void* in, int dtype, int64_t n_p
 int zk_launch_generic_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,
                             int64_t n_rows, double* out, hipStream_t s);
 
-// fast path (zk_fold.hip / zk_fast_*.hip)
+// direct parity-folded path (zk_fold.hip / zk_fast_frame.hip)
+int zk_full_set_nmax(const zk_plan* p);              // n_max if (n, m) is the full reference set, else -1
 int zk_fold_build(zk_plan* p, const double* basis);  // fills p->fold or leaves it null
 void zk_fold_free(zk_plan* p);
-bool zk_fast_patches_available(const zk_plan* p, int dtype);
 bool zk_fast_frame_available(const zk_plan* p, int dtype);
-int zk_launch_fast_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,
-                           hipStream_t s);
 int zk_launch_fast_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,
                          int64_t n_rows, double* out, hipStream_t s);
+
+// row-separable path (zk_sep.hip / zk_sep_frame.hip / zk_sep_patches.hip)
+int zk_sep_build(zk_plan* p, const double* basis);   // fills p->sep or leaves it null
+void zk_sep_free(zk_plan* p);
+bool zk_sep_frame_available(const zk_plan* p, int dtype);
+bool zk_sep_patches_available(const zk_plan* p, int dtype);
+int zk_launch_sep_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,
+                        int64_t n_rows, double* out, hipStream_t s);
+int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,
+                          hipStream_t s);

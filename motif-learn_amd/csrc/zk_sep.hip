@@ -1,0 +1,230 @@
+// zk_sep.hip -- host side of the row-separable path: builds the Legendre tables and the
+// Zernike <- Legendre-product matrix T of a plan (see zk_sep.h), in extended precision.
+#include <math.h>
+
+#include <algorithm>
+
+#include "zk_sep.h"
+
+typedef long double ld;
+
+static const int kSepNmax[] = {4, 6, 8, 10};  // instantiated kernels (zk_sep_frame/patches.hip)
+
+// x^a = sum_i L[a][i] P_i(x), from x P_i = ((i+1) P_{i+1} + i P_{i-1}) / (2i+1); all terms positive.
+static std::vector<std::vector<ld>> monomial_to_legendre(int deg) {
+  std::vector<std::vector<ld>> L(deg + 1, std::vector<ld>(deg + 2, 0.0L));
+  L[0][0] = 1.0L;
+  for (int a = 0; a < deg; ++a)
+    for (int i = 0; i <= a; ++i) {
+      const ld v = L[a][i];
+      if (v == 0.0L) continue;
+      L[a + 1][i + 1] += v * (ld)(i + 1) / (ld)(2 * i + 1);
+      if (i > 0) L[a + 1][i - 1] += v * (ld)i / (ld)(2 * i + 1);
+    }
+  return L;
+}
+
+static ld factl(int n) {
+  ld f = 1.0L;
+  for (int i = 2; i <= n; ++i) f *= (ld)i;
+  return f;
+}
+
+static ld binom(int n, int k) { return factl(n) / (factl(k) * factl(n - k)); }  // exact for n <= 20
+
+// Coefficients mono[a][b] of  R_n^{|m|}(rho) * (cos(m t) | sin(|m| t))  as a polynomial in x, y:
+//   rho^{k+2t} cos(k t) = (x^2+y^2)^t Re (x+iy)^k,  sin: Im  (reference _zps.py:52-64, 85-88).
+static void zernike_monomials(int n, int m, int deg, std::vector<ld>& mono) {
+  mono.assign((size_t)(deg + 1) * (deg + 1), 0.0L);
+  const int k = m < 0 ? -m : m;
+  for (int s = 0; s <= (n - k) / 2; ++s) {
+    const ld c = ((s & 1) ? -1.0L : 1.0L) * factl(n - s) /
+                 (factl(s) * factl((n + k) / 2 - s) * factl((n - k) / 2 - s));
+    const int t = (n - 2 * s - k) / 2;
+    for (int u = 0; u <= t; ++u)
+      for (int q = 0; q <= k; ++q) {
+        if ((m >= 0) == ((q & 1) != 0)) continue;  // cos keeps even q, sin keeps odd q
+        const int h = m >= 0 ? q / 2 : (q - 1) / 2;
+        const ld sg = (h & 1) ? -1.0L : 1.0L;
+        const int a = 2 * (t - u) + k - q, b = 2 * u + q;
+        mono[(size_t)a * (deg + 1) + b] += c * binom(t, u) * binom(k, q) * sg;
+      }
+  }
+}
+
+template <typename T>
+static int upload(T** dst, const std::vector<T>& src) {
+  if (src.empty()) return 0;
+  ZK_HIP(hipMalloc((void**)dst, src.size() * sizeof(T)));
+  ZK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+void zk_sep_free(zk_plan* p) {
+  zk_sep_tables* t = p->sep;
+  if (!t) return;
+  if (t->d_xq) (void)hipFree(t->d_xq);
+  if (t->d_T) (void)hipFree(t->d_T);
+  if (t->d_colmap) (void)hipFree(t->d_colmap);
+  if (t->d_rows) (void)hipFree(t->d_rows);
+  if (t->d_units) (void)hipFree(t->d_units);
+  delete t;
+  p->sep = nullptr;
+}
+
+int zk_sep_build(zk_plan* p, const double* basis) {
+  const int K = p->size, NP = p->n_poly;
+  const int n_max = zk_full_set_nmax(p);
+  if (n_max < 0 || K < 2) return 0;
+  int knm = -1;
+  for (int k : kSepNmax)
+    if (n_max <= k) {
+      knm = k;
+      break;
+    }
+  if (knm < 0) return 0;
+  const int npk = (knm + 1) * (knm + 2) / 2;
+  const int D = knm + 1;
+
+  // ---- grid and Legendre values (numpy.linspace arithmetic: start + i*step, exact endpoint) ----
+  std::vector<double> x(K);
+  const double step = 2.0 / (double)(K - 1);
+  for (int c = 0; c < K; ++c) x[c] = (double)c * step + -1.0;
+  x[K - 1] = 1.0;
+  std::vector<ld> P((size_t)K * D);
+  for (int c = 0; c < K; ++c) {
+    P[(size_t)c * D] = 1.0L;
+    if (D > 1) P[(size_t)c * D + 1] = (ld)x[c];
+    for (int i = 1; i + 1 < D; ++i)
+      P[(size_t)c * D + i + 1] = ((ld)(2 * i + 1) * (ld)x[c] * P[(size_t)c * D + i] - (ld)i * P[(size_t)c * D + i - 1]) / (ld)(i + 1);
+  }
+
+  // ---- T: Zernike j  <-  Legendre products (a, b), extended precision --------------------------
+  const auto L = monomial_to_legendre(knm);
+  std::vector<ld> Tfull((size_t)NP * D * D, 0.0L);  // [j][a][b]
+  std::vector<ld> mono;
+  for (int j = 0; j < NP; ++j) {
+    const int n = p->n[j], m = p->m[j];
+    zernike_monomials(n, m, knm, mono);
+    const ld norm = sqrtl((ld)(2 * (n + 1)) / (m == 0 ? 2.0L : 1.0L));
+    for (int a = 0; a <= knm; ++a)
+      for (int b = 0; a + b <= knm; ++b) {
+        const ld cf = mono[(size_t)a * D + b];
+        if (cf == 0.0L) continue;
+        for (int ia = 0; ia <= a; ++ia)
+          for (int ib = 0; ib <= b; ++ib)
+            Tfull[((size_t)j * D + ia) * D + ib] += cf * L[a][ia] * L[b][ib];
+      }
+    for (int t = 0; t < D * D; ++t) Tfull[(size_t)j * D * D + t] *= norm;
+  }
+
+  // ---- check the caller's basis: mirror-symmetric disk, contiguous row ranges, V == T P P ------
+  std::vector<char> disk((size_t)K * K, 0);
+  for (int r = 0; r < K; ++r)
+    for (int c = 0; c < K; ++c)
+      for (int j = 0; j < NP && !disk[(size_t)r * K + c]; ++j) disk[(size_t)r * K + c] = basis[((size_t)j * K + r) * K + c] != 0.0;
+  for (int r = 0; r < K; ++r)
+    for (int c = 0; c < K; ++c)
+      if (disk[(size_t)r * K + c] != disk[(size_t)r * K + (K - 1 - c)] ||
+          disk[(size_t)r * K + c] != disk[(size_t)(K - 1 - r) * K + c])
+        return 0;
+  const int Q = (K + 1) / 2;
+  std::vector<zk_sep_row> rows;
+  for (int r = 0; r < Q; ++r) {
+    int cmin = Q;
+    for (int c = Q - 1; c >= 0 && disk[(size_t)r * K + c]; --c) cmin = c;
+    for (int c = 0; c < cmin; ++c)
+      if (disk[(size_t)r * K + c]) return 0;  // not a suffix: cannot happen for a disk
+    if (cmin < Q) rows.push_back({r, cmin});
+  }
+  if (rows.empty()) return 0;
+  for (int j = 0; j < NP; ++j) {
+    double vmax = 0.0;
+    for (int t = 0; t < K * K; ++t) vmax = std::max(vmax, fabs(basis[(size_t)j * K * K + t]));
+    for (int r = 0; r < K; ++r)
+      for (int c = 0; c < K; ++c) {
+        if (!disk[(size_t)r * K + c]) continue;
+        ld v = 0.0L;
+        for (int a = 0; a <= knm; ++a)
+          for (int b = 0; a + b <= knm; ++b)
+            v += Tfull[((size_t)j * D + a) * D + b] * P[(size_t)c * D + a] * P[(size_t)r * D + b];
+        if (fabsl(v - (ld)basis[((size_t)j * K + r) * K + c]) > 1e-9L * (ld)vmax + 1e-300L) return 0;
+      }
+  }
+
+  // ---- device tables -----------------------------------------------------------------------
+  zk_sep_tables* t = new zk_sep_tables();
+  p->sep = t;
+  t->kernel_nmax = knm;
+  t->np_kernel = npk;
+  t->Q = Q;
+  t->tile_pitch = K + 63;
+  std::vector<double> xq((size_t)Q * ZK_SEP_ROW, 0.0);
+  for (int c = 0; c < Q; ++c) {
+    const double w = (c == K - 1 - c) ? 0.5 : 1.0;
+    for (int a = 0; a < D; ++a) xq[(size_t)c * ZK_SEP_ROW + a] = (double)(P[(size_t)c * D + a] * (ld)w);
+  }
+  // class-ordered slots: Zernike (rows of T) and Legendre products (columns of T)
+  std::vector<int32_t> colmap;
+  std::vector<double> Tdev;
+  const ld inv_area = 1.0L / (M_PIl * (ld)K * (ld)K / 4.0L);
+  for (int cls = 0; cls < 4; ++cls) {
+    std::vector<int> zj;  // plan column of each Zernike slot of this class (or -1)
+    int j = 0;
+    for (int n = 0; n <= knm; ++n)
+      for (int m = -n; m <= n; m += 2, ++j)
+        if (zk_class_of(m) == cls) zj.push_back(n <= n_max ? j : -1);
+    std::vector<std::pair<int, int>> ab;
+    for (int a = 0; a <= knm; ++a)
+      for (int b = 0; a + b <= knm; ++b) {
+        const int c2 = (a & 1) ? ((b & 1) ? ZK_OO : ZK_OE) : ((b & 1) ? ZK_EO : ZK_EE);
+        if (c2 == cls) ab.push_back({a, b});
+      }
+    if (zj.size() != ab.size()) return zk_fail(ZK_E_BADARG, "internal: class size mismatch");
+    for (size_t jj = 0; jj < zj.size(); ++jj) {
+      colmap.push_back(zj[jj]);
+      for (size_t ii = 0; ii < ab.size(); ++ii) {
+        ld v = 0.0L;
+        if (zj[jj] >= 0) v = Tfull[((size_t)zj[jj] * D + ab[ii].first) * D + ab[ii].second] * inv_area;
+        Tdev.push_back((double)v);
+      }
+    }
+  }
+  int rc;
+  if ((rc = upload(&t->d_xq, xq))) return rc;
+  t->d_yq = t->d_xq;  // same grid in x and y
+  if ((rc = upload(&t->d_T, Tdev))) return rc;
+  if ((rc = upload(&t->d_colmap, colmap))) return rc;
+  t->n_rows = (int)rows.size();
+  if ((rc = upload(&t->d_rows, rows))) return rc;
+
+  if (K % 32 == 0) {  // batch kernel: every quadrant row splits into whole 16-pixel units
+    t->run = (K == 32) ? 8 : 4;
+    std::vector<zk_sep_unit> units;
+    for (const zk_sep_row& row : rows) {
+      const int r = row.r, rm = K - 1 - r;
+      const size_t first = units.size();
+      for (int c0 = 0; c0 + 16 <= K / 2; c0 += 16) {
+        if (c0 + 16 <= row.cmin) continue;  // unit entirely outside the disk
+        zk_sep_unit u = {};
+        if (t->run == 8) {
+          u.run_off[0] = r * K * 4;
+          u.run_off[1] = rm * K * 4;
+        } else {
+          u.run_off[0] = (r * K + c0) * 4;
+          u.run_off[1] = (r * K + K - 16 - c0) * 4;
+          u.run_off[2] = (rm * K + c0) * 4;
+          u.run_off[3] = (rm * K + K - 16 - c0) * 4;
+        }
+        u.c0 = c0;
+        u.cmin = row.cmin;
+        u.r = r;
+        units.push_back(u);
+      }
+      if (units.size() > first) units.back().row_end = 1;
+    }
+    t->n_units = (int)units.size();
+    if ((rc = upload(&t->d_units, units))) return rc;
+  }
+  return 0;
+}

@@ -1,0 +1,108 @@
+// zk_sep_frame.hip -- dense-frame Zernike moments (reference _zps.py:159-193), row-separable form.
+//
+// Same decomposition as zk_fast_frame.hip: a 256-thread workgroup owns 4 rows x 64 columns of output
+// pixels, one output pixel per lane, the zero-padded (K+3) x (K+63) image tile staged once in LDS as
+// float64.  The arithmetic is the row-separable sum of zk_sep.h: per quadrant pixel 4 conflict-free
+// ds_read_b64, 8 v_add_f64 for the mirror folds and 2(n_max+1) v_fma_f64 whose Legendre operand is an
+// SGPR pair; per disk row N_poly v_fma_f64; one class-blocked T product at the end.  All scalar tables
+// together are ~7 KiB at (32, 8) and stay in the scalar data cache.
+//
+// Roofline: FP64-VALU-bound; algorithmic HBM bytes s_in + 8 N_poly per pixel.
+#include "zk_sep.h"
+
+namespace {
+
+template <int NMAX, typename T>
+__global__ __launch_bounds__(256) void zk_frame_sep_kernel(
+    const T* __restrict__ img, double* __restrict__ out, const zk_sep_row* __restrict__ rows,
+    const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
+    int n_tab_rows, int K, int H, int W, int row0, int n_rows, int tile_pitch) {
+  extern __shared__ __attribute__((aligned(16))) double tile[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int ea = K - 1 - (K - 1) / 2;
+  const int i0 = row0 + blockIdx.y * 4;
+  const int k0 = blockIdx.x * 64;
+  const int tile_elems = (K + 3) * tile_pitch;
+
+  for (int e = tid; e < tile_elems; e += 256) {
+    const int tr = e / tile_pitch;
+    const int tc = e - tr * tile_pitch;
+    const int ii = i0 - ea + tr;
+    const int kk = k0 - ea + tc;
+    double v = 0.0;
+    if (ii >= 0 && ii < H && kk >= 0 && kk < W) v = (double)img[(long long)ii * W + kk];
+    tile[e] = v;
+  }
+  __syncthreads();
+
+  zk_sep_acc<NMAX> acc;
+  acc.clear_all();
+  const double* __restrict__ mine = tile + wave * tile_pitch + lane;
+  const ZK_CONST int32_t* rtab = zk_const((const int32_t*)rows);
+  const ZK_CONST double* px = zk_const(xq);
+  const int Q = (K + 1) / 2;
+  for (int ri = 0; ri < n_tab_rows; ++ri) {
+    const int r = rtab[2 * ri], cmin = rtab[2 * ri + 1];
+    const double* __restrict__ top = mine + r * tile_pitch;
+    const double* __restrict__ bot = mine + (K - 1 - r) * tile_pitch;
+    for (int c = cmin; c < Q; ++c)
+      acc.pixel(top[c], top[K - 1 - c], bot[c], bot[K - 1 - c], px + c * ZK_SEP_ROW);
+    acc.row_end(px + r * ZK_SEP_ROW);
+  }
+
+  const int oi = i0 + wave;
+  const int ok = k0 + lane;
+  const bool live = oi < row0 + n_rows && ok < W;
+  const long long plane = (long long)n_rows * W;
+  double* __restrict__ dst = out + (long long)(oi - row0) * W + ok;
+  const ZK_CONST int32_t* cmap = zk_const(colmap);
+  acc.transform(zk_const(tmat), [&](int slot, double z) {
+    const int col = cmap[slot];
+    if (live && col >= 0) dst[col * plane] = z;
+  });
+}
+
+template <int NMAX, typename T>
+int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out,
+               hipStream_t s) {
+  const zk_sep_tables* t = p->sep;
+  const size_t lds = (size_t)(p->size + 3) * t->tile_pitch * sizeof(double);
+  auto kern = zk_frame_sep_kernel<NMAX, T>;
+  if (lds > 64 * 1024)
+    ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((unsigned)((W + 63) / 64), (unsigned)((n_rows + 3) / 4));
+  int rc = zk_prof_begin(p, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out, t->d_rows, t->d_xq, t->d_T, t->d_colmap,
+                     t->n_rows, p->size, (int)H, (int)W, (int)row0, (int)n_rows, t->tile_pitch);
+  ZK_HIP(hipGetLastError());
+  return zk_prof_end(p, s);
+}
+
+template <typename T>
+int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out,
+             hipStream_t s) {
+  switch (p->sep->kernel_nmax) {
+    case 4: return launch_one<4, T>(p, in, H, W, row0, n_rows, out, s);
+    case 6: return launch_one<6, T>(p, in, H, W, row0, n_rows, out, s);
+    case 8: return launch_one<8, T>(p, in, H, W, row0, n_rows, out, s);
+    case 10: return launch_one<10, T>(p, in, H, W, row0, n_rows, out, s);
+  }
+  return zk_fail(ZK_E_BADARG, "no separable frame kernel for this n_max");
+}
+
+}  // namespace
+
+bool zk_sep_frame_available(const zk_plan* p, int dtype) {
+  (void)dtype;
+  if (!p->sep || p->sep->n_rows == 0) return false;
+  return (size_t)(p->size + 3) * p->sep->tile_pitch * sizeof(double) <= 160 * 1024;
+}
+
+int zk_launch_sep_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                        double* out, hipStream_t s) {
+  if (dtype == ZK_F32) return launch_t<float>(p, in, H, W, row0, n_rows, out, s);
+  return launch_t<double>(p, in, H, W, row0, n_rows, out, s);
+}

@@ -1,0 +1,205 @@
+// zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157) for float32
+// patches: HBM-streaming, LDS-DMA transposed, row-separable arithmetic.
+//
+// Work decomposition.  One wave owns 64 consecutive patches, one patch per lane, and keeps that
+// patch's accumulators in VGPRs for the whole patch, so every multiplier that is not a pixel is
+// wave-uniform and arrives as an SGPR pair from a scalar load (no LDS or VGPR traffic for tables, no
+// cross-lane reduction).  HBM holds a patch contiguously while a lane needs "pixel t of my patch";
+// that transposition is done by the LDS-DMA engine:
+//
+//   unit    = 16 quadrant pixels of one row pair (r, K-1-r) for all 64 patches = 16 KiB.
+//   stage   = 16 global_load_lds_dwordx4; each instruction moves whole 128-B (RUN=8, K=32) or 64-B
+//             (RUN=4) runs of 8 / 16 patches, so HBM and the TCP see full-line requests (measured:
+//             6.1 TB/s for this access pattern alone, profiles/r01_micro_sfma.txt).  The LDS image is
+//             lane-linear per instruction; the granule a lane fetches is rotated by its patch index so
+//             that the later per-lane ds_read_b128 (lane = patch) is bank-conflict-free.
+//   consume = 16 ds_read_b128 pull the unit into 64 VGPRs, the wave immediately re-arms its LDS slab
+//             with the DMA of the next unit and computes from registers while that DMA is in flight.
+//
+// Arithmetic (zk_sep.h): per quadrant pixel 4 v_cvt + 8 v_add_f64 (mirror folds, exact for float32)
+// + 2(n_max+1) v_fma_f64; per row pair N_poly v_fma_f64; one class-blocked T product per patch.
+// The scalar tables (Legendre values, T) total ~7 KiB at (32, 8) and stay in the scalar data cache --
+// the direct folded sum streamed 76 KiB per wave through it and ran scalar-latency-bound
+// (profiles/r01_patch_fold_pmc.txt).
+//
+// No workgroup barrier exists in the kernel: a wave only ever reads LDS bytes it DMA'd itself (ordered
+// by its own s_waitcnt vmcnt(0)); the waves of a workgroup only share the allocation.  Rows fully
+// outside the unit disk (rows 0 and 31 at K=32) are never fetched.
+//
+// Epilogue: moments go through the same LDS slab to become rows of the (N, N_poly) output and are
+// stored as contiguous 16-B-per-lane runs.
+//
+// Roofline: algorithmic bytes K*K*4 + 8*N_poly per patch (4 456 B at (32, 8)); HBM-bound.
+#include "zk_sep.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+#define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int NMAX, int RUN>
+__global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
+    const float* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
+    const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
+    int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp) {
+  using S = zk_sep_set<NMAX>;
+  constexpr int NRUN = 16 / RUN;        // source runs per unit: 2 lines (RUN=8) or 4 half-lines
+  constexpr int PPI = 64 / RUN;         // patches covered by one DMA instruction
+  constexpr int SH = RUN == 8 ? 1 : 2;  // rotation = patch >> SH makes ds_read_b128 conflict-free
+  __shared__ __attribute__((aligned(16))) float lds[4 * 4096];  // 16 KiB per wave
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* const wl = lds + wave * 4096;
+  const long long patch0 = ((long long)blockIdx.x * 4 + wave) * 64;
+  if (patch0 >= n_patches) return;  // wave-uniform; the kernel has no workgroup barrier
+  const long long left = n_patches - patch0;
+  const int nv = left < 64 ? (int)left : 64;  // live patches of this wave
+
+  // ---- DMA addressing: lane -> (patch-in-group a, slot b) ---------------------------------------
+  const int a = lane / RUN, b = lane % RUN;
+  const int g0 = (b - (a >> SH)) & (RUN - 1);  // source granule for patch group 0
+  const char* const wbase = (const char*)in + patch0 * patch_bytes;
+  int poff[RUN];  // per patch group: byte offset of this lane's patch (+ its rotated granule)
+#pragma unroll
+  for (int pg = 0; pg < RUN; ++pg) {
+    int pi = pg * PPI + a;
+    pi = pi < nv ? pi : nv - 1;  // tail wave: re-read the last live patch
+    // rot(patch) = (pg*PPI + a) >> SH = 4*pg + (a >> SH) for both RUN values
+    const int g = (g0 - 4 * pg) & (RUN - 1);
+    poff[pg] = pi * patch_bytes + g * 16;
+  }
+  const ZK_CONST int32_t* utab = zk_const((const int32_t*)units);  // 8 ints per unit
+  auto issue = [&](int u) {
+#pragma unroll
+    for (int rho = 0; rho < NRUN; ++rho) {
+      const int ro = utab[8 * u + rho];
+#pragma unroll
+      for (int pg = 0; pg < RUN; ++pg) {
+        __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(wbase + (poff[pg] + ro)),
+                                         ZK_LDS_PTR(wl + (rho * RUN + pg) * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- LDS read addressing: lane = patch ----------------------------------------------------------
+  int rd[RUN];  // float index of granule g of this lane's patch inside a run image
+#pragma unroll
+  for (int g = 0; g < RUN; ++g) rd[g] = (lane * RUN + ((g + (lane >> SH)) & (RUN - 1))) * 4;
+
+  zk_sep_acc<NMAX> acc;
+  acc.clear_all();
+  const ZK_CONST double* px = zk_const(xq);
+
+  issue(0);
+  for (int u = 0; u < n_units; ++u) {
+    const int c0 = utab[8 * u + 4], cmin = utab[8 * u + 5], r = utab[8 * u + 6], rend = utab[8 * u + 7];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of unit u has landed
+    f32x4 R[NRUN][RUN];
+#pragma unroll
+    for (int rho = 0; rho < NRUN; ++rho)
+#pragma unroll
+      for (int g = 0; g < RUN; ++g) R[rho][g] = *(const f32x4*)(wl + rho * 64 * RUN * 4 + rd[g]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // unit is in VGPRs: the slab may be re-armed
+    if (u + 1 < n_units) issue(u + 1);
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (c0 + 4 * q + e >= cmin) {  // wave-uniform: quadrant pixel inside the disk
+          double pa, pb, pc, pd;
+          if constexpr (RUN == 8) {  // run 0 = row r (cols 0..31), run 1 = row K-1-r
+            pa = (double)R[0][q][e];
+            pb = (double)R[0][7 - q][3 - e];
+            pc = (double)R[1][q][e];
+            pd = (double)R[1][7 - q][3 - e];
+          } else {  // runs: (r, left 16), (r, mirrored right 16), (r', left), (r', right)
+            pa = (double)R[0][q][e];
+            pb = (double)R[1][3 - q][3 - e];
+            pc = (double)R[2][q][e];
+            pd = (double)R[3][3 - q][3 - e];
+          }
+          acc.pixel(pa, pb, pc, pd, px + (c0 + 4 * q + e) * ZK_SEP_ROW);
+        }
+      }
+    }
+    if (rend) acc.row_end(px + r * ZK_SEP_ROW);
+  }
+
+  // ---- Z = T M, then (patch, column) rows via LDS -> 16-B stores ------------------------------------
+  double z[S::NP];
+  acc.transform(zk_const(tmat), [&](int slot, double v) { z[slot] = v; });
+  const ZK_CONST int32_t* cmap = zk_const(colmap);
+  double* const slab = (double*)wl;  // 2048 doubles; ppp = patches per pass (host: largest power of
+                                     // two with ppp * n_poly <= 2048)
+  double* const obase = out + patch0 * n_poly;
+  for (int h = 0; h * ppp < 64; ++h) {
+    if (lane / ppp == h) {
+      double* const row = slab + (lane % ppp) * n_poly;
+#pragma unroll
+      for (int i = 0; i < S::NP; ++i) {
+        const int col = cmap[i];
+        if (col >= 0) row[col] = z[i];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int live = nv - h * ppp;
+    live = live < 0 ? 0 : (live > ppp ? ppp : live);
+    const int vd = live * n_poly;  // doubles to write in this pass
+    double* const dst = obase + (long long)h * ppp * n_poly;
+    for (int k = lane; 2 * k < vd; k += 64) {
+      const f64x2 v = *(const f64x2*)(slab + 2 * k);
+      if (2 * k + 2 <= vd) {
+        *(f64x2*)(dst + 2 * k) = v;
+      } else {
+        dst[2 * k] = v.x;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next pass overwrites
+  }
+}
+
+template <int NMAX, int RUN>
+int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
+  const zk_sep_tables* t = p->sep;
+  const long long waves = (n_patches + 63) / 64;
+  const long long blocks = (waves + 3) / 4;
+  if (blocks > 0x7fffffffLL) return zk_fail(ZK_E_BADARG, "too many patches for one launch");
+  int ppp = 64;
+  while (ppp * p->n_poly > 2048) ppp >>= 1;
+  int rc = zk_prof_begin(p, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL((zk_patch_sep_kernel<NMAX, RUN>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)in,
+                     out, t->d_units, t->d_xq, t->d_T, t->d_colmap, t->n_units, p->n_poly, (long long)n_patches,
+                     p->size * p->size * 4, ppp);
+  ZK_HIP(hipGetLastError());
+  return zk_prof_end(p, s);
+}
+
+template <int RUN>
+int launch_run(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
+  switch (p->sep->kernel_nmax) {
+    case 4: return launch_one<4, RUN>(p, in, n_patches, out, s);
+    case 6: return launch_one<6, RUN>(p, in, n_patches, out, s);
+    case 8: return launch_one<8, RUN>(p, in, n_patches, out, s);
+    case 10: return launch_one<10, RUN>(p, in, n_patches, out, s);
+  }
+  return zk_fail(ZK_E_BADARG, "no batch kernel for this n_max");
+}
+
+}  // namespace
+
+bool zk_sep_patches_available(const zk_plan* p, int dtype) {
+  const zk_sep_tables* t = p->sep;
+  return t && dtype == ZK_F32 && t->n_units > 0 && p->n_poly <= 1024;
+}
+
+int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {
+  if (((uintptr_t)in & 15) || ((uintptr_t)out & 15))  // 16-B DMA granules and 16-B stores
+    return zk_launch_generic_patches(p, in, dtype, n_patches, out, s);
+  return p->sep->run == 8 ? launch_run<8>(p, in, n_patches, out, s) : launch_run<4>(p, in, n_patches, out, s);
+}

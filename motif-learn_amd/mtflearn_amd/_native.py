@@ -13,7 +13,8 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, 
 import numpy as np
 
 ZK_F32, ZK_F64 = 0, 1
-PATH_AUTO, PATH_GENERIC, PATH_FAST = 0, 1, 2
+PATH_AUTO, PATH_GENERIC, PATH_FOLDED, PATH_SEPARABLE = 0, 1, 2, 3
+PATH_NAMES = {PATH_GENERIC: "generic", PATH_FOLDED: "folded", PATH_SEPARABLE: "separable"}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libzernike_hip.so")
 
@@ -25,7 +26,7 @@ SYMBOLS = {
     "zk_plan_create": (c_int, [c_int, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_double),
                                c_int, POINTER(c_void_p)]),
     "zk_plan_destroy": (None, [c_void_p]),
-    "zk_plan_has_fast": (c_int, [c_void_p, c_int, c_int]),
+    "zk_plan_has_path": (c_int, [c_void_p, c_int, c_int, c_int]),
     "zk_plan_disk_pixels": (c_int, [c_void_p]),
     "zk_plan_set_path": (c_int, [c_void_p, c_int]),
     "zk_transform_patches": (c_int, [c_void_p, c_void_p, c_int, c_int64, POINTER(c_double)]),
@@ -40,6 +41,25 @@ SYMBOLS = {
 _lib = None
 
 
+def _preload_torch_hip():
+    """When PyTorch-ROCm is installed it ships its own ``libamdhip64.so`` (SONAME libamdhip64.so.7).
+    Two HIP runtimes in one process do not coexist (the second one finds no device), so bind our
+    library to torch's copy: loading it first satisfies our NEEDED libamdhip64.so.7 by SONAME, and a
+    later ``import torch`` resolves to the same file.  Without torch the system ROCm runtime is used."""
+    if os.environ.get("MTFLEARN_AMD_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        for base in (spec.submodule_search_locations or []) if spec else []:
+            cand = os.path.join(base, "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+                return
+    except Exception:
+        pass
+
+
 def load():
     """Load the shared library once; raises RuntimeError when it has not been built."""
     global _lib
@@ -50,6 +70,7 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C motif-learn_amd/csrc` (hipcc, --offload-arch=gfx950). "
             "mtflearn_amd has no CPU fallback.")
+    _preload_torch_hip()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
@@ -114,8 +135,14 @@ class Plan:
     __del__ = close
 
     # -- introspection / control -------------------------------------------------------
-    def has_fast(self, mode, dtype_code_):
-        return bool(self._lib.zk_plan_has_fast(self._h, mode, dtype_code_))
+    def has_path(self, mode, dtype_code_, path):
+        """True if kernel family ``path`` exists for mode (0 batch, 1 frame) and element type."""
+        return bool(self._lib.zk_plan_has_path(self._h, mode, dtype_code_, path))
+
+    def best_path(self, mode, dtype_code_):
+        for path in (PATH_SEPARABLE, PATH_FOLDED, PATH_GENERIC):
+            if self.has_path(mode, dtype_code_, path):
+                return path
 
     @property
     def disk_pixels(self):

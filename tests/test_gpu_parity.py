@@ -35,16 +35,17 @@ def _zps(n_max, size):
 
 
 def _both_paths(native, z, array, mode):
-    """Moments from every kernel family the plan has for this input, keyed by name."""
+    """Moments from every kernel family the plan has for this input (generic / folded / separable),
+    keyed by name."""
     plan = z._device_plan()
     run = plan.transform_patches if mode == 0 else plan.transform_frame
     out = {}
-    plan.set_path(native.PATH_GENERIC)
-    out["generic"] = run(array)
-    if plan.has_fast(mode, native.dtype_code(array.dtype)):
-        plan.set_path(native.PATH_FAST)
-        out["fast"] = run(array)
+    for path, name in native.PATH_NAMES.items():
+        if plan.has_path(mode, native.dtype_code(array.dtype), path):
+            plan.set_path(path)
+            out[name] = run(array)
     plan.set_path(native.PATH_AUTO)
+    assert "generic" in out
     return out
 
 
@@ -60,7 +61,7 @@ def _both_paths(native, z, array, mode):
 def test_patches_golden(native, golden, key_in, key_out, n_max, size, expect_fast):
     z = _zps(n_max, size)
     res = _both_paths(native, z, np.ascontiguousarray(golden[key_in]), 0)
-    assert ("fast" in res) == expect_fast
+    assert ("separable" in res) == expect_fast
     for name, got in res.items():
         assert got.dtype == np.float64 and got.shape == golden[key_out].shape
         rel_close(got, golden[key_out])
@@ -91,7 +92,7 @@ def test_frame_golden(native, golden, zo):
     ref = golden["Zf_frame_f64cast_8_32"]
     for arr in (img32, img32.astype(np.float64)):          # float32 values are exact in float64
         res = _both_paths(native, z8, arr, 1)
-        assert "fast" in res
+        assert "folded" in res and "separable" in res
         for got in res.values():
             assert got.shape == ref.shape and got.dtype == np.float64
             rel_close(got, ref)
@@ -130,6 +131,7 @@ def test_patches_ragged_counts(native, zo, n_patches):
     (8, 64, np.float32),      # RUN=4 batch kernel (64-B runs)
     (10, 64, np.float32),
     (4, 32, np.float32), (5, 32, np.float32), (6, 32, np.float32), (7, 32, np.float32), (9, 48, np.float32),
+    (9, 32, np.float32), (1, 32, np.float32), (3, 64, np.float32), (10, 96, np.float32),
     (8, 32, np.float64), (3, 16, np.float32), (6, 33, np.float32), (8, 72, np.float32), (0, 5, np.float64),
     (12, 64, np.float64), (0, 1, np.float32),
 ])
@@ -198,9 +200,9 @@ def test_c_abi_argument_errors(native):
                               n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                               z.polynomials.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 99,
                               ctypes.byref(handle)) == -10001                     # bad device index
-    with pytest.raises(RuntimeError, match="no fast"):
+    with pytest.raises(RuntimeError, match="not available"):
         big = _zps(12, 64)._device_plan()
-        big.set_path(native.PATH_FAST)
+        big.set_path(native.PATH_SEPARABLE)
         big.transform_patches(np.zeros((2, 64, 64), np.float32))
 
 
