@@ -32,6 +32,21 @@
 // Roofline: algorithmic bytes K*K*4 + 8*N_poly per patch (4 456 B at (32, 8)); HBM-bound.
 #include "zk_sep.h"
 
+// Timing-only ablation builds (make ABLATE=n -> libzernike_hip_ablate<n>.so; outputs are wrong by
+// construction): 1 = no arithmetic (DMA + LDS reads + stores), 2 = no DMA (arithmetic on stale LDS),
+// 3 = no output stores.  cdna_hip_programming.md section 5.4 rule 17: stubbed values are kept live.
+#ifndef ZK_ABLATE
+#define ZK_ABLATE 0
+#endif
+// cache policy of the streamed operands: aux = 2 is "nt" (non-temporal) on the LDS-DMA loads of the
+// patches (each byte is read exactly once by one CU) and on the moment stores
+#ifndef ZK_DMA_AUX
+#define ZK_DMA_AUX 0
+#endif
+#ifndef ZK_STORE_NT
+#define ZK_STORE_NT 0
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -80,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
 #pragma unroll
       for (int pg = 0; pg < RUN; ++pg) {
         __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(wbase + (poff[pg] + ro)),
-                                         ZK_LDS_PTR(wl + (rho * RUN + pg) * 256), 16, 0, 0);
+                                         ZK_LDS_PTR(wl + (rho * RUN + pg) * 256), 16, 0, ZK_DMA_AUX);
       }
     }
   };
@@ -94,7 +109,9 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
   acc.clear_all();
   const ZK_CONST double* px = zk_const(xq);
 
+#if ZK_ABLATE != 2
   issue(0);
+#endif
   for (int u = 0; u < n_units; ++u) {
     const int c0 = utab[8 * u + 4], cmin = utab[8 * u + 5], r = utab[8 * u + 6], rend = utab[8 * u + 7];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of unit u has landed
@@ -104,8 +121,17 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
 #pragma unroll
       for (int g = 0; g < RUN; ++g) R[rho][g] = *(const f32x4*)(wl + rho * 64 * RUN * 4 + rd[g]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // unit is in VGPRs: the slab may be re-armed
+#if ZK_ABLATE != 2
     if (u + 1 < n_units) issue(u + 1);
+#endif
 
+#if ZK_ABLATE == 1
+#pragma unroll
+    for (int rho = 0; rho < NRUN; ++rho)
+#pragma unroll
+      for (int g = 0; g < RUN; ++g) asm volatile("" ::"v"(R[rho][g]));
+    if (false)
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -127,7 +153,9 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
         }
       }
     }
+#if ZK_ABLATE != 1
     if (rend) acc.row_end(px + r * ZK_SEP_ROW);
+#endif
   }
 
   // ---- Z = T M, then (patch, column) rows via LDS -> 16-B stores ------------------------------------
@@ -153,11 +181,19 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
     double* const dst = obase + (long long)h * ppp * n_poly;
     for (int k = lane; 2 * k < vd; k += 64) {
       const f64x2 v = *(const f64x2*)(slab + 2 * k);
+#if ZK_ABLATE == 3
+      asm volatile("" ::"v"(v));
+#else
       if (2 * k + 2 <= vd) {
+#if ZK_STORE_NT
+        __builtin_nontemporal_store(v, (f64x2*)(dst + 2 * k));
+#else
         *(f64x2*)(dst + 2 * k) = v;
+#endif
       } else {
         dst[2 * k] = v.x;
       }
+#endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next pass overwrites
   }

@@ -16,7 +16,9 @@ ZK_F32, ZK_F64 = 0, 1
 PATH_AUTO, PATH_GENERIC, PATH_FOLDED, PATH_SEPARABLE = 0, 1, 2, 3
 PATH_NAMES = {PATH_GENERIC: "generic", PATH_FOLDED: "folded", PATH_SEPARABLE: "separable"}
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libzernike_hip.so")
+# MTFLEARN_AMD_LIB: alternative build of the same ABI (e.g. a timing-only ablation variant)
+LIB_PATH = os.environ.get("MTFLEARN_AMD_LIB") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "lib", "libzernike_hip.so")
 
 # every symbol include/zernike_hip.h declares: (restype, argtypes)
 SYMBOLS = {
