@@ -153,6 +153,10 @@ extern "C" int zk_plan_create(int size, int n_poly, const int32_t* n, const int3
     e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e != hipSuccess) rc = zk_hip_fail(e, "hipStreamCreate");
   }
+  if (!rc) {
+    e = hipDeviceGetAttribute(&p->n_cu, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess || p->n_cu <= 0) rc = zk_hip_fail(e, "hipDeviceGetAttribute(MultiprocessorCount)");
+  }
   if (!rc) rc = build_generic_tables(p, basis);
   if (!rc) rc = zk_fold_build(p, basis);
   if (!rc) rc = zk_sep_build(p, basis);

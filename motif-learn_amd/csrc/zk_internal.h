@@ -22,6 +22,7 @@ struct zk_plan {
   int size = 0;
   int n_poly = 0;
   int device = 0;
+  int n_cu = 256;                // compute units of the device (persistent grids)
   int path = ZK_PATH_AUTO;
   std::vector<int32_t> n, m;
 
