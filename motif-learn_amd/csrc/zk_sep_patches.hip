@@ -117,44 +117,53 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
   for (int u = 0; u < n_units; ++u) {
     const int c0 = utab[8 * u + 4], cmin = utab[8 * u + 5], r = utab[8 * u + 6], rend = utab[8 * u + 7];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of unit u has landed
-    f32x4 R[NRUN][RUN];
+    // The unit is consumed in two halves of 8 quadrant pixels so that only 32 staging VGPRs are live:
+    // the outer half first (quadrant columns c0..c0+7, often entirely outside the disk and then not even
+    // read), then the inner half; the slab is re-armed as soon as the inner half is in registers.
+    auto lds_granule = [&](int rho, int g) -> f32x4 {
+      return *(const f32x4*)(wl + rho * 64 * RUN * 4 + rd[g]);
+    };
+    auto half = [&](int q0, bool rearm) {  // quadrant granules q0, q0+1 of both rows and their mirrors
+      f32x4 A[2], B[2], C[2], D[2];       // A: (r, q)  B: (r, mirror of q)  C, D: same for row K-1-r
 #pragma unroll
-    for (int rho = 0; rho < NRUN; ++rho)
-#pragma unroll
-      for (int g = 0; g < RUN; ++g) R[rho][g] = *(const f32x4*)(wl + rho * 64 * RUN * 4 + rd[g]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // unit is in VGPRs: the slab may be re-armed
-#if ZK_ABLATE != 2
-    if (u + 1 < n_units) issue(u + 1);
-#endif
-
-#if ZK_ABLATE == 1
-#pragma unroll
-    for (int rho = 0; rho < NRUN; ++rho)
-#pragma unroll
-      for (int g = 0; g < RUN; ++g) asm volatile("" ::"v"(R[rho][g]));
-    if (false)
-#endif
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (c0 + 4 * q + e >= cmin) {  // wave-uniform: quadrant pixel inside the disk
-          double pa, pb, pc, pd;
-          if constexpr (RUN == 8) {  // run 0 = row r (cols 0..31), run 1 = row K-1-r
-            pa = (double)R[0][q][e];
-            pb = (double)R[0][7 - q][3 - e];
-            pc = (double)R[1][q][e];
-            pd = (double)R[1][7 - q][3 - e];
-          } else {  // runs: (r, left 16), (r, mirrored right 16), (r', left), (r', right)
-            pa = (double)R[0][q][e];
-            pb = (double)R[1][3 - q][3 - e];
-            pc = (double)R[2][q][e];
-            pd = (double)R[3][3 - q][3 - e];
-          }
-          acc.pixel(pa, pb, pc, pd, px + (c0 + 4 * q + e) * ZK_SEP_ROW);
+      for (int i = 0; i < 2; ++i) {
+        const int q = q0 + i;
+        if constexpr (RUN == 8) {  // run 0 = row r (cols 0..31), run 1 = row K-1-r
+          A[i] = lds_granule(0, q);
+          B[i] = lds_granule(0, 7 - q);
+          C[i] = lds_granule(1, q);
+          D[i] = lds_granule(1, 7 - q);
+        } else {  // runs: (r, left 16), (r, mirrored right 16), (r', left), (r', right)
+          A[i] = lds_granule(0, q);
+          B[i] = lds_granule(1, 3 - q);
+          C[i] = lds_granule(2, q);
+          D[i] = lds_granule(3, 3 - q);
         }
       }
-    }
+      if (rearm) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // unit is in VGPRs: the slab may be re-armed
+#if ZK_ABLATE != 2
+        if (u + 1 < n_units) issue(u + 1);
+#endif
+      }
+#if ZK_ABLATE == 1
+#pragma unroll
+      for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(A[i]), "v"(B[i]), "v"(C[i]), "v"(D[i]));
+      if (false)
+#endif
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = c0 + 4 * (q0 + i) + e;
+          if (c >= cmin)  // wave-uniform: quadrant pixel inside the disk
+            acc.pixel((double)A[i][e], (double)B[i][3 - e], (double)C[i][e], (double)D[i][3 - e],
+                      px + c * ZK_SEP_ROW);
+        }
+      }
+    };
+    if (cmin < c0 + 8) half(0, false);
+    half(2, true);
 #if ZK_ABLATE != 1
     if (rend) acc.row_end(px + r * ZK_SEP_ROW);
 #endif
