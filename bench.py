@@ -98,12 +98,20 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
         args.gpus = world
+    # Rehearsal knobs (a 1-GPU box cannot run RCCL between two ranks): ZK_BENCH_BACKEND=gloo with
+    # ZK_BENCH_ONE_DEVICE=1 puts every rank on device 0 and exercises the same control flow.
+    backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")
+    if os.environ.get("ZK_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     os.environ["MTFLEARN_AMD_DEVICE"] = str(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mtflearn_amd import ZPs, _native
     from mtflearn_amd.synthetic import honeycomb_frame
@@ -163,9 +171,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
 
-    # ---- all-gather alone (reported beside the pipelined number) ---------------------------------
+    # ---- all-gather alone (reported beside the pipelined number) + check of the gathered matrix ----
     allgather_ms = None
+    gathered_ok = None
     if gather:
+        last = (args.steps - 1) & 1
+        mine = fulls[last][rank * n_local:(rank + 1) * n_local]
+        ok = torch.tensor([int(torch.equal(mine, outs[last]))], device=dev)
+        # every rank's block must have arrived: the first row of each block is finite and non-zero
+        heads = fulls[last][::n_local, 0]
+        ok &= int(bool(torch.isfinite(heads).all() and (heads != 0).all()))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        gathered_ok = bool(ok.item())
         fence()
         t1 = time.perf_counter()
         for _ in range(3):
@@ -210,7 +227,8 @@ def main():
         "kernel_only_patches_per_s": world * n_local / (kern_ms * 1e-3),
     }
     if allgather_ms is not None:
-        result["allgather"] = {"ms_alone": allgather_ms, "bytes_per_rank_out": n_local * n_poly * 8,
+        result["allgather"] = {"ms_alone": allgather_ms, "verified": gathered_ok,
+                               "bytes_per_rank_out": n_local * n_poly * 8,
                                "gathered_bytes": world * n_local * n_poly * 8}
 
     # ---- dense-frame kernels on the same frame (side measurement, not `value`) -----------------------
