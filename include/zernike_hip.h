@@ -105,6 +105,27 @@ int zk_transform_frame_dev(zk_plan* plan, const void* image_dev, int dtype, int6
                            void* hip_stream);
 
 /*
+ * Fused dense pipeline: frame -> per-pixel symmetry maps, without writing the (n_poly, H, W) moments
+ * to memory (reference notebook-3 tail: zmoments.to_complex / rot_maps / mirror_map,
+ * _zmoments.py:300-316, 420-493).  Any of the three outputs may be NULL.
+ *   abs_out    : (N_c, n_rows, W)      |Z_{n,m} + i Z_{n,-m}| of the raw moments, (n, m>=0) in the
+ *                                      order of to_complex(), N_c = number of (n, |m|) pairs
+ *   rot_out    : (n_folds, n_rows, W)  zmoments.rot_maps(folds, p, m_unselect); n_folds <= 8
+ *   mirror_out : (n_rows, W)           zmoments.mirror_map(theta, p, m_unselect)
+ *   m_unselect : |m| values to drop (must contain 0; reference default (0, 1));  p_norm: 2, or 0 for None
+ *   theta      : host, n_theta angles in radians (reference default linspace(0, 2 pi, 360, endpoint=False))
+ * Needs the row-separable tables (zk_plan_has_path(plan, 1, dtype, ZK_PATH_SEPARABLE)); otherwise fails
+ * and the caller composes zk_transform_frame with the host-side container methods.
+ */
+int zk_frame_maps(zk_plan* plan, const void* image_host, int dtype, int64_t height, int64_t width,
+                  const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
+                  const double* theta, int n_theta, double* rot_host, double* abs_host, double* mirror_host);
+int zk_frame_maps_dev(zk_plan* plan, const void* image_dev, int dtype, int64_t height, int64_t width,
+                      int64_t row0, int64_t n_rows, const int32_t* folds, int n_folds,
+                      const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta, int n_theta,
+                      double* rot_dev, double* abs_dev, double* mirror_dev, void* hip_stream);
+
+/*
  * Kernel timing with HIP events on the stream the kernels are launched on.
  * zk_plan_profile(plan, 1) brackets every subsequent kernel launch with an event pair;
  * zk_plan_profile_read() synchronises, returns the launch count and summed kernel

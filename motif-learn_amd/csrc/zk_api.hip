@@ -294,3 +294,60 @@ extern "C" int zk_transform_frame(zk_plan* p, const void* image_host, int dtype,
   ZK_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }
+
+// ------------------------------------------------------------------------------------
+// fused symmetry maps
+// ------------------------------------------------------------------------------------
+static int complex_count(int n_max) {
+  int k = 0;
+  for (int n = 0; n <= n_max; ++n) k += n / 2 + 1;
+  return k;
+}
+
+extern "C" int zk_frame_maps_dev(zk_plan* p, const void* image, int dtype, int64_t H, int64_t W, int64_t row0,
+                                 int64_t n_rows, const int32_t* folds, int n_folds, const int32_t* m_unselect,
+                                 int n_unselect, int p_norm, const double* theta, int n_theta, double* rot,
+                                 double* ab, double* mirror, void* hip_stream) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  int rc = check_dtype(dtype);
+  if (rc) return rc;
+  if (H <= 0 || W <= 0 || H > 0x3fffffff || W > 0x3fffffff) return zk_fail(ZK_E_BADARG, "bad frame shape");
+  if (row0 < 0 || n_rows < 0 || row0 + n_rows > H) return zk_fail(ZK_E_BADARG, "row band outside the frame");
+  if (n_rows == 0) return 0;
+  if (!image) return zk_fail(ZK_E_BADARG, "null device pointer");
+  if (!m_unselect || n_unselect <= 0) return zk_fail(ZK_E_BADARG, "m=0 must be included in m_unselect.");
+  ZK_HIP(hipSetDevice(p->device));
+  return zk_launch_sep_maps(p, image, dtype, H, W, row0, n_rows, folds, n_folds, m_unselect, n_unselect, p_norm,
+                            theta, n_theta, rot, ab, mirror, (hipStream_t)hip_stream);
+}
+
+extern "C" int zk_frame_maps(zk_plan* p, const void* image_host, int dtype, int64_t H, int64_t W,
+                             const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect,
+                             int p_norm, const double* theta, int n_theta, double* rot_host, double* abs_host,
+                             double* mirror_host) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  int rc = check_dtype(dtype);
+  if (rc) return rc;
+  if (H <= 0 || W <= 0) return zk_fail(ZK_E_BADARG, "bad frame shape");
+  if (!image_host) return zk_fail(ZK_E_BADARG, "null host pointer");
+  ZK_HIP(hipSetDevice(p->device));
+  const size_t px = (size_t)H * W;
+  const int nc = complex_count(zk_full_set_nmax(p));
+  const size_t in_bytes = px * elem_size(dtype);
+  const size_t rot_d = rot_host ? (size_t)n_folds * px : 0, abs_d = abs_host ? (size_t)nc * px : 0,
+               mir_d = mirror_host ? px : 0;
+  if ((rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes))) return rc;
+  if ((rc = ensure((void**)&p->d_out, &p->d_out_bytes, (rot_d + abs_d + mir_d + 1) * sizeof(double)))) return rc;
+  double* d_rot = rot_host ? p->d_out : nullptr;
+  double* d_abs = abs_host ? p->d_out + rot_d : nullptr;
+  double* d_mir = mirror_host ? p->d_out + rot_d + abs_d : nullptr;
+  ZK_HIP(hipMemcpyAsync(p->d_in, image_host, in_bytes, hipMemcpyHostToDevice, p->stream));
+  if ((rc = zk_frame_maps_dev(p, p->d_in, dtype, H, W, 0, H, folds, n_folds, m_unselect, n_unselect, p_norm, theta,
+                              n_theta, d_rot, d_abs, d_mir, p->stream)))
+    return rc;
+  if (rot_host) ZK_HIP(hipMemcpyAsync(rot_host, d_rot, rot_d * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  if (abs_host) ZK_HIP(hipMemcpyAsync(abs_host, d_abs, abs_d * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  if (mirror_host) ZK_HIP(hipMemcpyAsync(mirror_host, d_mir, mir_d * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  ZK_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}

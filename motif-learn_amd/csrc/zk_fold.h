@@ -32,6 +32,55 @@ struct zk_set {
   }
   static constexpr int EE = count(ZK_EE), OE = count(ZK_OE), EO = count(ZK_EO), OO = count(ZK_OO);
   static constexpr int NP = EE + OE + EO + OO;
+  static constexpr int cls_of_m(int m) {
+    const int am = m < 0 ? -m : m;
+    return m >= 0 ? ((am & 1) ? ZK_OE : ZK_EE) : ((am & 1) ? ZK_EO : ZK_OO);
+  }
+  // class-ordered slot of (n, m): classes in order EE, OE, EO, OO; ascending reference index inside
+  static constexpr int slot_of(int n, int m) {
+    int k = 0;
+    for (int cls = 0; cls < 4; ++cls)
+      for (int nn = 0; nn <= NMAX; ++nn)
+        for (int mm = -nn; mm <= nn; mm += 2)
+          if (cls_of_m(mm) == cls) {
+            if (nn == n && mm == m) return k;
+            ++k;
+          }
+    return -1;
+  }
+  static constexpr int slot_n(int slot) {
+    int k = 0;
+    for (int cls = 0; cls < 4; ++cls)
+      for (int nn = 0; nn <= NMAX; ++nn)
+        for (int mm = -nn; mm <= nn; mm += 2)
+          if (cls_of_m(mm) == cls) {
+            if (k == slot) return nn;
+            ++k;
+          }
+    return -1;
+  }
+  static constexpr int slot_m(int slot) {
+    int k = 0;
+    for (int cls = 0; cls < 4; ++cls)
+      for (int nn = 0; nn <= NMAX; ++nn)
+        for (int mm = -nn; mm <= nn; mm += 2)
+          if (cls_of_m(mm) == cls) {
+            if (k == slot) return mm;
+            ++k;
+          }
+    return -1;
+  }
+  // index of the complex moment (n, |m|) in the reference's to_complex() order (n, then m ascending)
+  static constexpr int complex_index(int n, int am) {
+    int k = 0;
+    for (int nn = 0; nn <= NMAX; ++nn)
+      for (int mm = nn & 1; mm <= nn; mm += 2) {
+        if (nn == n && mm == am) return k;
+        ++k;
+      }
+    return -1;
+  }
+  static constexpr int NC = complex_index(NMAX, NMAX) + 1;
 };
 
 inline int zk_class_of(int m) {

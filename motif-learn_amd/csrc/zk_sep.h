@@ -105,6 +105,8 @@ struct zk_sep_tables {
   int n_rows = 0;
   zk_sep_row* d_rows = nullptr;    // [n_rows]
   int tile_pitch = 0;
+  double* d_trig = nullptr;        // fused maps: [n_theta][2][ZK_SEP_ROW] cos / sin(m theta), per call
+  size_t trig_doubles = 0;
   // batch kernel (float32, K % 32 == 0)
   int run = 0;
   int n_units = 0;
@@ -161,28 +163,41 @@ struct zk_sep_acc {
     clear_row();
   }
 
-  // Z (class-ordered Zernike slots) = T * M, one parity class at a time; `emit(slot, value)` receives
-  // each finished moment.  tb walks the class blocks of the T table ([cls][j][i], row-major).
-  template <int CLS, typename F>
-  __device__ __forceinline__ void transform_class(const ZK_CONST double*& tb, F&& emit) {
+  // Z (class-ordered Zernike slots) = T * M, one parity class at a time.  `emit(slot, value)` receives
+  // each finished moment; `slot` is a std::integral_constant, so callers can use it both as an int
+  // and (decltype(slot)::value) as a compile-time constant.  The T table is [cls][j][i], row-major.
+  template <int CLS>
+  static constexpr int t_offset() {
+    int o = 0;
+    for (int c = 0; c < CLS; ++c) o += S::cls_count(c) * S::cls_count(c);
+    return o;
+  }
+  template <int CLS, int J, typename F>
+  __device__ __forceinline__ void transform_row(const ZK_CONST double* tmat, F&& emit) {
     constexpr int n = S::cls_count(CLS), off = S::cls_begin(CLS);
+    const ZK_CONST double* tb = tmat + t_offset<CLS>() + J * n;
+    double z = 0.0;
 #pragma unroll
-    for (int j = 0; j < n; ++j) {
-      double z = 0.0;
-#pragma unroll
-      for (int i = 0; i < n; ++i) z = __builtin_fma(tb[j * n + i], M[off + i], z);
-      emit(off + j, z);
-      // keep the scheduler from hoisting every row's scalar loads to the top (hundreds of SGPRs)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    tb += n * n;
+    for (int i = 0; i < n; ++i) z = __builtin_fma(tb[i], M[off + i], z);
+    emit(std::integral_constant<int, off + J>{}, z);
+    // keep the scheduler from hoisting every row's scalar loads to the top (hundreds of SGPRs)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  template <int CLS, typename F, int... Js>
+  __device__ __forceinline__ void transform_rows(const ZK_CONST double* tmat, F&& emit,
+                                                 std::integer_sequence<int, Js...>) {
+    (transform_row<CLS, Js>(tmat, emit), ...);
+  }
+  template <int CLS, typename F>
+  __device__ __forceinline__ void transform_class(const ZK_CONST double* tmat, F&& emit) {
+    transform_rows<CLS>(tmat, emit, std::make_integer_sequence<int, S::cls_count(CLS)>{});
   }
   template <typename F>
-  __device__ __forceinline__ void transform(const ZK_CONST double* tb, F&& emit) {
-    transform_class<ZK_EE>(tb, emit);
-    transform_class<ZK_OE>(tb, emit);
-    transform_class<ZK_EO>(tb, emit);
-    transform_class<ZK_OO>(tb, emit);
+  __device__ __forceinline__ void transform(const ZK_CONST double* tmat, F&& emit) {
+    transform_class<ZK_EE>(tmat, emit);
+    transform_class<ZK_OE>(tmat, emit);
+    transform_class<ZK_EO>(tmat, emit);
+    transform_class<ZK_OO>(tmat, emit);
   }
 };
 #endif

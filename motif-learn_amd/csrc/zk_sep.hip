@@ -68,6 +68,7 @@ void zk_sep_free(zk_plan* p) {
   if (t->d_colmap) (void)hipFree(t->d_colmap);
   if (t->d_rows) (void)hipFree(t->d_rows);
   if (t->d_units) (void)hipFree(t->d_units);
+  if (t->d_trig) (void)hipFree(t->d_trig);
   delete t;
   p->sep = nullptr;
 }

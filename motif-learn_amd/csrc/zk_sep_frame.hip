@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void zk_frame_sep_kernel(
   const long long plane = (long long)n_rows * W;
   double* __restrict__ dst = out + (long long)(oi - row0) * W + ok;
   const ZK_CONST int32_t* cmap = zk_const(colmap);
-  acc.transform(zk_const(tmat), [&](int slot, double z) {
+  acc.transform(zk_const(tmat), [&](auto slot, double z) {
     const int col = cmap[slot];
     if (live && col >= 0) dst[col * plane] = z;
   });

@@ -1,0 +1,249 @@
+// zk_sep_maps.hip -- fused dense pipeline: frame -> per-pixel symmetry maps, without materialising
+// the (N_poly, H, W) moments in HBM (BASELINE configs[4]).
+//
+// What it computes, per output pixel, from the moments Z of the pixel's window (zk_sep_frame.hip):
+//   abs   [(n,|m|)] = |Z_{n,m} + i Z_{n,-m}|                      np.abs(zm.to_complex().data)   _zmoments.py:300-316
+//   rot   [f]       = sum_j w_{f,|m_j|} Z_j^2 / ||Z_sel||^2        zm.rot_maps(folds, p=2)        _zmoments.py:420-462
+//   mirror          = max_theta sum_k Re[(Zhat^c_k)^2 e^{-i m_k theta}]   zm.mirror_map(theta)    _zmoments.py:464-493
+// with "sel" = moments whose |m| is not in m_unselect (default (0,1)) and Zhat = Z_sel / ||Z_sel||_2
+// (p = 2; p = None skips the normalisation).  Since ||.|| is a positive per-pixel scalar it is applied
+// once at the end: rot = (sum w Z^2) / ||Z||^2,  mirror = max_theta(sum_m C_m cos m theta + S_m sin m theta) / ||Z||^2
+// with C_m = sum_n (A^2 - B^2), S_m = sum_n 2AB, A = Z_{n,m}, B = Z_{n,-m}.
+//
+// Register discipline: the T product (zk_sep.h) emits one parity class at a time; +m and -m of the
+// same (n, |m|) live in partner classes (EE<->OO for even m, OE<->EO for odd m), so only one class of
+// moments is ever held while its partner class is being produced and folded into the running sums.
+// Algorithmic HBM bytes: s_in + 8 (n_folds + N_c + 1) per pixel instead of s_in + 8 N_poly written and
+// read again by a separate map pass.
+#include "zk_sep.h"
+
+#define ZK_MAX_FOLDS 8
+
+struct zk_maps_params {
+  int n_folds;
+  int unselect_mask;   // bit am set: moments with |m| == am are dropped (bit 0 always set)
+  int normalize;       // 1: p = 2, 0: p = None
+  int n_theta;
+  int plan_nmax;       // moments with n > plan_nmax are padding of the kernel set
+  int pad_;
+  double w[ZK_MAX_FOLDS][ZK_SEP_ROW];  // fold weights by |m| (reference construct_rot_maps_matrix)
+};
+
+namespace {
+
+template <typename F, int... Is>
+__device__ __forceinline__ void zk_for_each_int(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
+template <int NMAX, typename T>
+__global__ __launch_bounds__(256) void zk_frame_maps_kernel(
+    const T* __restrict__ img, const zk_sep_row* __restrict__ rows, const double* __restrict__ xq,
+    const double* __restrict__ tmat, const double* __restrict__ trig, double* __restrict__ rot_out,
+    double* __restrict__ abs_out, double* __restrict__ mirror_out, zk_maps_params prm, int n_tab_rows, int K, int H,
+    int W, int row0, int n_rows, int tile_pitch) {
+  using Z = zk_set<NMAX>;
+  extern __shared__ __attribute__((aligned(16))) double tile[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int ea = K - 1 - (K - 1) / 2;
+  const int i0 = row0 + blockIdx.y * 4;
+  const int k0 = blockIdx.x * 64;
+  const int tile_elems = (K + 3) * tile_pitch;
+
+  for (int e = tid; e < tile_elems; e += 256) {
+    const int tr = e / tile_pitch;
+    const int tc = e - tr * tile_pitch;
+    const int ii = i0 - ea + tr;
+    const int kk = k0 - ea + tc;
+    double v = 0.0;
+    if (ii >= 0 && ii < H && kk >= 0 && kk < W) v = (double)img[(long long)ii * W + kk];
+    tile[e] = v;
+  }
+  __syncthreads();
+
+  zk_sep_acc<NMAX> acc;
+  acc.clear_all();
+  const double* __restrict__ mine = tile + wave * tile_pitch + lane;
+  const ZK_CONST int32_t* rtab = zk_const((const int32_t*)rows);
+  const ZK_CONST double* px = zk_const(xq);
+  const int Q = (K + 1) / 2;
+  for (int ri = 0; ri < n_tab_rows; ++ri) {
+    const int r = rtab[2 * ri], cmin = rtab[2 * ri + 1];
+    const double* __restrict__ top = mine + r * tile_pitch;
+    const double* __restrict__ bot = mine + (K - 1 - r) * tile_pitch;
+    for (int c = cmin; c < Q; ++c)
+      acc.pixel(top[c], top[K - 1 - c], bot[c], bot[K - 1 - c], px + c * ZK_SEP_ROW);
+    acc.row_end(px + r * ZK_SEP_ROW);
+  }
+
+  // ---- fused tail ---------------------------------------------------------------------------------
+  const int oi = i0 + wave;
+  const int ok = k0 + lane;
+  const bool live = oi < row0 + n_rows && ok < W;
+  const long long plane = (long long)n_rows * W;
+  const long long pix = (long long)(oi - row0) * W + ok;
+
+  double norm2 = 0.0;
+  double rot[ZK_MAX_FOLDS];
+#pragma unroll
+  for (int f = 0; f < ZK_MAX_FOLDS; ++f) rot[f] = 0.0;
+  double Cm[NMAX + 1], Sm[NMAX + 1];
+#pragma unroll
+  for (int m = 0; m <= NMAX; ++m) Cm[m] = Sm[m] = 0.0;
+
+  // one complex moment (n, am) with real part A = Z_{n,+am} and imaginary part B = Z_{n,-am}
+  auto combine = [&](auto nn, auto amm, double A, double B) {
+    constexpr int n = decltype(nn)::value, am = decltype(amm)::value;
+    const double a2 = A * A, b2 = B * B;
+    if (abs_out != nullptr && live && n <= prm.plan_nmax)
+      abs_out[Z::complex_index(n, am) * plane + pix] = __builtin_sqrt(a2 + b2);
+    if (!((prm.unselect_mask >> am) & 1)) {
+      const double e2 = a2 + b2;
+      norm2 += e2;
+#pragma unroll
+      for (int f = 0; f < ZK_MAX_FOLDS; ++f)
+        if (f < prm.n_folds) rot[f] = __builtin_fma(prm.w[f][am], e2, rot[f]);
+      Cm[am] += a2 - b2;
+      Sm[am] = __builtin_fma(2.0 * A, B, Sm[am]);
+    }
+  };
+
+  const ZK_CONST double* tb = zk_const(tmat);
+  constexpr int KEEP = Z::EE > Z::OE ? Z::EE : Z::OE;
+  double keep[KEEP > 0 ? KEEP : 1];
+  // even m: cos terms (class EE, includes m = 0) then their sin partners (class OO)
+  constexpr int offEE = 0, offOE = Z::EE;  // class-ordered slots: [EE | OE | EO | OO]
+  acc.template transform_class<ZK_EE>(tb, [&](auto slot, double v) { keep[decltype(slot)::value - offEE] = v; });
+  acc.template transform_class<ZK_OO>(tb, [&](auto slot, double v) {
+    constexpr int s = decltype(slot)::value;
+    constexpr int n = Z::slot_n(s), am = -Z::slot_m(s);
+    combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{},
+            keep[Z::slot_of(n, am) - offEE], v);
+  });
+  // m = 0 has no partner
+  zk_for_each_int(
+      [&](auto i) {
+        constexpr int n = 2 * decltype(i)::value;
+        combine(std::integral_constant<int, n>{}, std::integral_constant<int, 0>{}, keep[Z::slot_of(n, 0) - offEE], 0.0);
+      },
+      std::make_integer_sequence<int, NMAX / 2 + 1>{});
+  // odd m: cos terms (class OE) then their sin partners (class EO)
+  acc.template transform_class<ZK_OE>(tb, [&](auto slot, double v) { keep[decltype(slot)::value - offOE] = v; });
+  acc.template transform_class<ZK_EO>(tb, [&](auto slot, double v) {
+    constexpr int s = decltype(slot)::value;
+    constexpr int n = Z::slot_n(s), am = -Z::slot_m(s);
+    combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{},
+            keep[Z::slot_of(n, am) - offOE], v);
+  });
+
+  const double inv = prm.normalize ? 1.0 / norm2 : 1.0;  // 0/0 -> NaN exactly where NumPy gives NaN
+  if (rot_out != nullptr && live) {
+#pragma unroll
+    for (int f = 0; f < ZK_MAX_FOLDS; ++f)
+      if (f < prm.n_folds) rot_out[f * plane + pix] = rot[f] * inv;
+  }
+  if (mirror_out != nullptr) {
+    const ZK_CONST double* cs = zk_const(trig);  // [n_theta][2][ZK_SEP_ROW]: cos(m theta), sin(m theta)
+    double best = -__builtin_inf();
+    for (int i = 0; i < prm.n_theta; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int m = 0; m <= NMAX; ++m) {
+        s = __builtin_fma(Cm[m], cs[(2 * i) * ZK_SEP_ROW + m], s);
+        s = __builtin_fma(Sm[m], cs[(2 * i + 1) * ZK_SEP_ROW + m], s);
+      }
+      best = s > best || s != s ? s : best;  // NaN propagates like numpy.max
+    }
+    if (live) mirror_out[pix] = best * inv;
+  }
+}
+
+template <int NMAX, typename T>
+int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+               const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
+               hipStream_t s) {
+  const zk_sep_tables* t = p->sep;
+  const size_t lds = (size_t)(p->size + 3) * t->tile_pitch * sizeof(double);
+  auto kern = zk_frame_maps_kernel<NMAX, T>;
+  if (lds > 64 * 1024)
+    ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((unsigned)((W + 63) / 64), (unsigned)((n_rows + 3) / 4));
+  int rc = zk_prof_begin(p, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, t->d_rows, t->d_xq, t->d_T, d_trig, rot, ab, mirror,
+                     prm, t->n_rows, p->size, (int)H, (int)W, (int)row0, (int)n_rows, t->tile_pitch);
+  ZK_HIP(hipGetLastError());
+  return zk_prof_end(p, s);
+}
+
+template <typename T>
+int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+             const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror, hipStream_t s) {
+  switch (p->sep->kernel_nmax) {
+    case 4: return launch_one<4, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 6: return launch_one<6, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 8: return launch_one<8, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 10: return launch_one<10, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+  }
+  return zk_fail(ZK_E_BADARG, "no fused maps kernel for this n_max");
+}
+
+}  // namespace
+
+int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                       const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
+                       const double* theta, int n_theta, double* rot, double* ab, double* mirror, hipStream_t s) {
+  if (!zk_sep_frame_available(p, dtype)) return zk_fail(ZK_E_BADARG, "plan has no separable frame kernel");
+  if (n_folds < 0 || n_folds > ZK_MAX_FOLDS) return zk_fail(ZK_E_BADARG, "at most 8 folds per call");
+  if (p_norm != 0 && p_norm != 2) return zk_fail(ZK_E_BADARG, "p must be 2 or 0 (None)");
+  if (rot && (!folds || n_folds == 0)) return zk_fail(ZK_E_BADARG, "rot output requested without folds");
+  if (mirror && (!theta || n_theta <= 0)) return zk_fail(ZK_E_BADARG, "mirror output requested without theta");
+  const int knm = p->sep->kernel_nmax;
+  zk_maps_params prm = {};
+  prm.n_folds = rot ? n_folds : 0;
+  prm.normalize = p_norm == 2;
+  prm.n_theta = mirror ? n_theta : 0;
+  prm.plan_nmax = zk_full_set_nmax(p);
+  prm.unselect_mask = 0;
+  for (int k = 0; k < n_unselect; ++k) {
+    const int am = m_unselect[k] < 0 ? -m_unselect[k] : m_unselect[k];
+    if (am < 31) prm.unselect_mask |= 1 << am;
+  }
+  if (!(prm.unselect_mask & 1)) return zk_fail(ZK_E_BADARG, "m=0 must be included in m_unselect.");
+  for (int f = 0; f < prm.n_folds; ++f) {
+    const int fold = folds[f];
+    if (fold <= 0) return zk_fail(ZK_E_BADARG, "folds must be positive");
+    for (int am = 0; am <= knm; ++am) {
+      // reference construct_rot_maps_matrix (_zmoments.py:199-235): 1 where |m| % fold == 0 and |m| > 1,
+      // 0 for |m| in {0, 1}, -1/(fold-1) elsewhere (0 when fold == 1)
+      double w;
+      if (am <= 1) w = 0.0;
+      else if (am % fold == 0) w = 1.0;
+      else w = fold > 1 ? -1.0 / (double)(fold - 1) : 0.0;
+      prm.w[f][am] = w;
+    }
+  }
+  if (prm.n_theta > 0) {
+    std::vector<double> tr((size_t)n_theta * 2 * ZK_SEP_ROW, 0.0);
+    for (int i = 0; i < n_theta; ++i)
+      for (int m = 0; m <= knm; ++m) {
+        tr[((size_t)2 * i) * ZK_SEP_ROW + m] = cos((double)m * theta[i]);
+        tr[((size_t)2 * i + 1) * ZK_SEP_ROW + m] = sin((double)m * theta[i]);
+      }
+    zk_sep_tables* t = p->sep;
+    if (t->trig_doubles < tr.size()) {
+      if (t->d_trig) ZK_HIP(hipFree(t->d_trig));
+      t->d_trig = nullptr;
+      ZK_HIP(hipMalloc((void**)&t->d_trig, tr.size() * sizeof(double)));
+      t->trig_doubles = tr.size();
+    }
+    // stream-ordered upload: a previous launch on `s` may still be reading the table
+    ZK_HIP(hipMemcpyAsync(t->d_trig, tr.data(), tr.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    ZK_HIP(hipStreamSynchronize(s));  // tr is a stack-lifetime host buffer
+  }
+  if (dtype == ZK_F32)
+    return launch_t<float>(p, in, H, W, row0, n_rows, prm, p->sep->d_trig, rot, ab, mirror, s);
+  return launch_t<double>(p, in, H, W, row0, n_rows, prm, p->sep->d_trig, rot, ab, mirror, s);
+}

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
 
   // ---- Z = T M, then (patch, column) rows via LDS -> 16-B stores ------------------------------------
   double z[S::NP];
-  acc.transform(zk_const(tmat), [&](int slot, double v) { z[slot] = v; });
+  acc.transform(zk_const(tmat), [&](auto slot, double v) { z[slot] = v; });
   const ZK_CONST int32_t* cmap = zk_const(colmap);
   double* const slab = (double*)wl;  // 2048 doubles; ppp = patches per pass (host: largest power of
                                      // two with ppp * n_poly <= 2048)

@@ -36,6 +36,12 @@ SYMBOLS = {
     "zk_transform_frame": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, POINTER(c_double)]),
     "zk_transform_frame_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
                                        c_void_p, c_void_p]),
+    "zk_frame_maps": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, POINTER(c_int32), c_int,
+                              POINTER(c_int32), c_int, c_int, POINTER(c_double), c_int, c_void_p, c_void_p,
+                              c_void_p]),
+    "zk_frame_maps_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, POINTER(c_int32),
+                                  c_int, POINTER(c_int32), c_int, c_int, POINTER(c_double), c_int, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
     "zk_plan_profile": (c_int, [c_void_p, c_int]),
     "zk_plan_profile_read": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
 }
@@ -178,6 +184,37 @@ class Plan:
                                            out.ctypes.data_as(POINTER(c_double))),
               "zk_transform_frame")
         return out
+
+    def frame_maps(self, image, n_complex, folds=None, m_unselect=(0, 1), p=2, theta=None, want_abs=True):
+        """Fused frame -> (rot_maps, |Z^c|, mirror_map); any of them None when not requested."""
+        code = dtype_code(image.dtype)
+        h, w = image.shape
+        folds32 = np.ascontiguousarray(folds if folds is not None else [], dtype=np.int32)
+        unsel32 = np.ascontiguousarray(m_unselect, dtype=np.int32)
+        rot = np.empty((len(folds32), h, w)) if len(folds32) else None
+        ab = np.empty((n_complex, h, w)) if want_abs else None
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        mir = np.empty((h, w)) if th is not None else None
+        ptr = lambda a: a.ctypes.data_as(c_void_p) if a is not None else None
+        check(self._lib.zk_frame_maps(
+            self._h, image.ctypes.data_as(c_void_p), code, h, w,
+            folds32.ctypes.data_as(POINTER(c_int32)), len(folds32),
+            unsel32.ctypes.data_as(POINTER(c_int32)), len(unsel32), 2 if p == 2 else 0,
+            th.ctypes.data_as(POINTER(c_double)) if th is not None else None, 0 if th is None else len(th),
+            ptr(rot), ptr(ab), ptr(mir)), "zk_frame_maps")
+        return rot, ab, mir
+
+    def frame_maps_dev(self, image_ptr, code, height, width, row0, n_rows, folds, m_unselect, p, theta,
+                       rot_ptr, abs_ptr, mirror_ptr, stream=0):
+        folds32 = np.ascontiguousarray(folds if folds is not None else [], dtype=np.int32)
+        unsel32 = np.ascontiguousarray(m_unselect, dtype=np.int32)
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        check(self._lib.zk_frame_maps_dev(
+            self._h, c_void_p(image_ptr), code, height, width, row0, n_rows,
+            folds32.ctypes.data_as(POINTER(c_int32)), len(folds32),
+            unsel32.ctypes.data_as(POINTER(c_int32)), len(unsel32), 2 if p == 2 else 0,
+            th.ctypes.data_as(POINTER(c_double)) if th is not None else None, 0 if th is None else len(th),
+            c_void_p(rot_ptr), c_void_p(abs_ptr), c_void_p(mirror_ptr), c_void_p(stream)), "zk_frame_maps_dev")
 
     # -- device-pointer entry points (bench / multi-GPU harness) ------------------------------
     def transform_patches_dev(self, patches_ptr, code, n_patches, out_ptr, stream=0):

@@ -146,6 +146,68 @@ class ZPs(BaseEstimator, TransformerMixin):
             return self._transform_patches(images)
         raise ValueError("Images must be 2D or 3D array.")
 
+    def symmetry_maps(self, image, n_folds=(2, 3, 4, 6), p=2, m_unselect=(0, 1), theta=None,
+                      abs_moments=True, mirror=True):
+        """Frame -> symmetry maps in one fused pass on the GPU (extension; not in the reference API).
+
+        Equivalent to ``zm = self.transform(image)`` followed by ``zm.rot_maps(n_folds, p, m_unselect)``,
+        ``np.abs(zm.to_complex().data)`` and ``zm.mirror_map(theta, p, m_unselect)`` (reference
+        ``_zmoments.py:300-316, 420-493``), but the ``(N_poly, H, W)`` moments never leave the chip.
+        Returns a dict with ``rot_maps (len(n_folds), H, W)``, ``abs (N_c, H, W)`` with its ``abs_n`` /
+        ``abs_m`` labels, ``mirror_map (H, W)`` (entries present only when requested) and ``valid_mask``.
+        Falls back to the unfused composition (device transform + the container's NumPy methods) for
+        shapes or options the fused kernel does not cover (``p`` other than 2 / None, more than 8 folds,
+        n_max > 10, odd tail cases where the separable tables are unavailable)."""
+        image = np.asarray(image)
+        if image.ndim != 2:
+            raise ValueError("symmetry_maps needs a 2D image.")
+        height, width = image.shape
+        if height < self.size or width < self.size:
+            raise ValueError(
+                f"For FFT convolution, image size ({height}x{width}) must be at least "
+                f"as large as polynomial size ({self.size}x{self.size})")
+        if m_unselect is None:
+            m_unselect = (0, 1)
+        if 0 not in m_unselect:
+            raise ValueError("m=0 must be included in m_unselect.")
+        folds = [] if n_folds is None else list(np.atleast_1d(n_folds).ravel())
+        if mirror and theta is None:
+            theta = np.linspace(0, 2 * np.pi, 360, endpoint=False)
+        complex_n = np.array([n for n in range(self.n_max + 1) for _ in range(n % 2, n + 1, 2)])
+        complex_m = np.array([m for n in range(self.n_max + 1) for m in range(n % 2, n + 1, 2)])
+        operand = self._device_operand(image)
+        plan = self._device_plan()
+        code = _native.dtype_code(operand.dtype)
+        fused = (plan.has_path(1, code, _native.PATH_SEPARABLE) and p in (2, None) and len(folds) <= 8
+                 and all(int(f) == f and f > 0 for f in folds))
+        out = {}
+        if fused:
+            rot, ab, mir = plan.frame_maps(operand, len(complex_n), folds=folds, m_unselect=m_unselect, p=p,
+                                           theta=theta if mirror else None, want_abs=abs_moments)
+        else:
+            zm = self._transform_frame(image)
+            rot = zm.rot_maps(folds, p=p, m_unselect=m_unselect) if folds else None
+            ab = np.abs(zm.to_complex().data) if abs_moments else None
+            mir = zm.mirror_map(theta=theta, p=p, m_unselect=m_unselect) if mirror else None
+        if rot is not None:
+            out["rot_maps"] = rot
+        if ab is not None:
+            out["abs"], out["abs_n"], out["abs_m"] = ab, complex_n, complex_m
+        if mir is not None:
+            out["mirror_map"] = mir
+        out["valid_mask"] = self._valid_mask(height, width)   # same convention as zmoments.valid_mask
+        return out
+
+    def _valid_mask(self, height, width):
+        head = (self.size - 1) // 2
+        tail = self.size - 1 - head
+        mask = np.ones((height, width), dtype=bool)
+        mask[:head, :] = False
+        mask[-tail:, :] = False
+        mask[:, :head] = False
+        mask[:, -tail:] = False
+        return mask
+
     def _transform_patches(self, images):
         _, height, width = images.shape
         if height != self.size or width != self.size:

@@ -116,6 +116,49 @@ def test_frame_tail_pipeline_golden(golden):
     rel_close(np.abs(zm.to_complex().data), np.abs(golden["pp3_complex"]), rtol=1e-8)
 
 
+def test_fused_symmetry_maps(native, golden, zo):
+    """Fused frame -> maps kernel against the reference's tail on the golden frame and against the
+    host container composed with the device transform on random frames (all option combinations)."""
+    z = _zps(6, 12)
+    img = golden["frame_f32_24_28"]
+    maps = z.symmetry_maps(img)
+    rel_close(maps["rot_maps"], golden["pp3_rot_maps"], rtol=1e-8)
+    rel_close(maps["mirror_map"], golden["pp3_mirror"], rtol=1e-8)
+    rel_close(maps["abs"], np.abs(golden["pp3_complex"]), rtol=1e-8)
+    np.testing.assert_array_equal(maps["valid_mask"], golden["pp3_valid_mask"])
+    zc_n, zc_m, _ = zo.to_complex(golden["pp3_moments"], z.n, z.m)[1], zo.to_complex(golden["pp3_moments"], z.n, z.m)[2], None
+    np.testing.assert_array_equal(maps["abs_n"], zc_n)
+    np.testing.assert_array_equal(maps["abs_m"], zc_m)
+    rng = np.random.default_rng(77)
+    for n_max, size, shape, dtype in [(8, 32, (70, 90), np.float32), (10, 32, (40, 130), np.float64),
+                                      (5, 16, (33, 65), np.float32), (7, 33, (40, 50), np.float32)]:
+        zz = _zps(n_max, size)
+        frame = (rng.random(shape) + 0.1).astype(dtype)
+        zm = zz.transform(frame)
+        for kwargs in [dict(), dict(n_folds=[3], p=None), dict(n_folds=[2, 3, 4, 5, 6, 8], m_unselect=(0, 1, 2)),
+                       dict(n_folds=None, abs_moments=False), dict(mirror=False, n_folds=[1, 2]),
+                       dict(theta=np.linspace(0, np.pi, 37))]:
+            got = zz.symmetry_maps(frame, **kwargs)
+            folds = kwargs.get("n_folds", (2, 3, 4, 6))
+            unsel = kwargs.get("m_unselect", (0, 1))
+            pp = kwargs.get("p", 2)
+            if folds is not None:
+                rel_close(got["rot_maps"], zm.rot_maps(folds, p=pp, m_unselect=unsel), rtol=1e-8, atol_scale=1e-11)
+            else:
+                assert "rot_maps" not in got
+            if kwargs.get("abs_moments", True):
+                rel_close(got["abs"], np.abs(zm.to_complex().data), rtol=1e-8, atol_scale=1e-11)
+            else:
+                assert "abs" not in got
+            if kwargs.get("mirror", True):
+                rel_close(got["mirror_map"], zm.mirror_map(theta=kwargs.get("theta"), p=pp, m_unselect=unsel),
+                          rtol=1e-8, atol_scale=1e-11)
+            else:
+                assert "mirror_map" not in got
+    with pytest.raises(ValueError, match="m=0 must be included"):
+        z.symmetry_maps(img, m_unselect=(1,))
+
+
 # ------------------------------------------------------------------ oracle on seeded inputs, edge cases
 @pytest.mark.parametrize("n_patches", [1, 2, 63, 64, 65, 130, 257, 1000])
 def test_patches_ragged_counts(native, zo, n_patches):
