@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-allgather", action="store_true", help="N>1: time the kernels only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-frame side measurement")
+    ap.add_argument("--no-maps", action="store_true", help="skip the configs[4] symmetry-map side measurement")
     return ap.parse_args()
 
 
@@ -258,6 +259,40 @@ def main():
         plan.set_path(_native.PATH_AUTO)
         result["dense_frame"] = dense
         del out_f
+
+    # ---- configs[4]: full symmetry-map pipeline, 4096^2, n_max = 10, fused on device (side measurement) ---
+    if not args.no_maps and world == 1:
+        from mtflearn_amd.distributed import frame_maps_device
+        del patches, outs
+        torch.cuda.empty_cache()
+        z10 = ZPs(n_max=10, size=K)
+        plan10 = z10._device_plan()
+        big = torch.from_numpy(honeycomb_frame(4096, seed=1)).to(dev)
+        theta = np.linspace(0, 2 * np.pi, 360, endpoint=False)
+        n_c = sum(n // 2 + 1 for n in range(11))
+        if plan10.has_path(1, _native.ZK_F32, _native.PATH_SEPARABLE):
+            frame_maps_device(plan10, big, n_c, theta=theta)
+            torch.cuda.synchronize()
+            plan10.profile(True)
+            for _ in range(3):
+                frame_maps_device(plan10, big, n_c, theta=theta)
+            torch.cuda.synchronize()
+            ln, ms = plan10.profile_read()
+            mom = frame_moments_device(plan10, big)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                frame_moments_device(plan10, big, out=mom)
+            torch.cuda.synchronize()
+            ln2, ms2 = plan10.profile_read()
+            plan10.profile(False)
+            result["symmetry_pipeline"] = {
+                "workload": "configs[4]: 4096x4096 frame, 32-px, n_max=10 -> rot_maps[2,3,4,6] + 36 |Z_nm| planes + "
+                            "mirror_map(360 angles), fused in one kernel",
+                "fused_kernel_ms": ms / ln, "positions_per_s": 4096 * 4096 / (ms / ln * 1e-3),
+                "moments_only_kernel_ms": ms2 / ln2,
+                "out_bytes_fused": 41 * 4096 * 4096 * 8, "out_bytes_moments": 66 * 4096 * 4096 * 8}
+            del mom
+        del big
 
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(z, frame, K)

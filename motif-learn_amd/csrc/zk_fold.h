@@ -81,6 +81,24 @@ struct zk_set {
     return -1;
   }
   static constexpr int NC = complex_index(NMAX, NMAX) + 1;
+  static constexpr int complex_n(int k) {
+    int i = 0;
+    for (int nn = 0; nn <= NMAX; ++nn)
+      for (int mm = nn & 1; mm <= nn; mm += 2) {
+        if (i == k) return nn;
+        ++i;
+      }
+    return -1;
+  }
+  static constexpr int complex_m(int k) {
+    int i = 0;
+    for (int nn = 0; nn <= NMAX; ++nn)
+      for (int mm = nn & 1; mm <= nn; mm += 2) {
+        if (i == k) return mm;
+        ++i;
+      }
+    return -1;
+  }
 };
 
 inline int zk_class_of(int m) {

@@ -183,6 +183,14 @@ struct zk_sep_acc {
     // keep the scheduler from hoisting every row's scalar loads to the top (hundreds of SGPRs)
     __builtin_amdgcn_sched_barrier(0);
   }
+  // one moment by its class-ordered Zernike slot (zk_set<NMAX> order: [EE | OE | EO | OO])
+  template <int SLOT>
+  __device__ __forceinline__ double moment(const ZK_CONST double* tmat) {
+    constexpr int cls = SLOT < S::cls_begin(1) ? 0 : SLOT < S::cls_begin(2) ? 1 : SLOT < S::cls_begin(3) ? 2 : 3;
+    double z = 0.0;
+    transform_row<cls, SLOT - S::cls_begin(cls)>(tmat, [&](auto, double v) { z = v; });
+    return z;
+  }
   template <int CLS, typename F, int... Js>
   __device__ __forceinline__ void transform_rows(const ZK_CONST double* tmat, F&& emit,
                                                  std::integer_sequence<int, Js...>) {

@@ -10,11 +10,12 @@
 // once at the end: rot = (sum w Z^2) / ||Z||^2,  mirror = max_theta(sum_m C_m cos m theta + S_m sin m theta) / ||Z||^2
 // with C_m = sum_n (A^2 - B^2), S_m = sum_n 2AB, A = Z_{n,m}, B = Z_{n,-m}.
 //
-// Register discipline: the T product (zk_sep.h) emits one parity class at a time; +m and -m of the
-// same (n, |m|) live in partner classes (EE<->OO for even m, OE<->EO for odd m), so only one class of
-// moments is ever held while its partner class is being produced and folded into the running sums.
+// Register discipline: the rows of the T product (zk_sep.h) are evaluated pair by pair -- Z_{n,+m} and
+// Z_{n,-m} back to back -- and folded into 3 (n_max+1) running sums, so no moment array ever exists.
 // Algorithmic HBM bytes: s_in + 8 (n_folds + N_c + 1) per pixel instead of s_in + 8 N_poly written and
 // read again by a separate map pass.
+#include <math.h>
+
 #include "zk_sep.h"
 
 #define ZK_MAX_FOLDS 8
@@ -25,8 +26,7 @@ struct zk_maps_params {
   int normalize;       // 1: p = 2, 0: p = None
   int n_theta;
   int plan_nmax;       // moments with n > plan_nmax are padding of the kernel set
-  int pad_;
-  double w[ZK_MAX_FOLDS][ZK_SEP_ROW];  // fold weights by |m| (reference construct_rot_maps_matrix)
+  int theta_sym;       // 1: theta is the uniform grid 2 pi k / n_theta with n_theta % 4 == 0 (see below)
 };
 
 namespace {
@@ -37,7 +37,7 @@ __device__ __forceinline__ void zk_for_each_int(F&& f, std::integer_sequence<int
 }
 
 template <int NMAX, typename T>
-__global__ __launch_bounds__(256) void zk_frame_maps_kernel(
+__global__ __launch_bounds__(256, (NMAX <= 8 ? 3 : 2)) void zk_frame_maps_kernel(
     const T* __restrict__ img, const zk_sep_row* __restrict__ rows, const double* __restrict__ xq,
     const double* __restrict__ tmat, const double* __restrict__ trig, double* __restrict__ rot_out,
     double* __restrict__ abs_out, double* __restrict__ mirror_out, zk_maps_params prm, int n_tab_rows, int K, int H,
@@ -85,13 +85,10 @@ __global__ __launch_bounds__(256) void zk_frame_maps_kernel(
   const long long plane = (long long)n_rows * W;
   const long long pix = (long long)(oi - row0) * W + ok;
 
-  double norm2 = 0.0;
-  double rot[ZK_MAX_FOLDS];
+  // per-|m| sums over n of the complex moments A + iB:  E = A^2 + B^2,  C = A^2 - B^2,  S = 2AB
+  double Em[NMAX + 1], Cm[NMAX + 1], Sm[NMAX + 1];
 #pragma unroll
-  for (int f = 0; f < ZK_MAX_FOLDS; ++f) rot[f] = 0.0;
-  double Cm[NMAX + 1], Sm[NMAX + 1];
-#pragma unroll
-  for (int m = 0; m <= NMAX; ++m) Cm[m] = Sm[m] = 0.0;
+  for (int m = 0; m <= NMAX; ++m) Em[m] = Cm[m] = Sm[m] = 0.0;
 
   // one complex moment (n, am) with real part A = Z_{n,+am} and imaginary part B = Z_{n,-am}
   auto combine = [&](auto nn, auto amm, double A, double B) {
@@ -99,62 +96,84 @@ __global__ __launch_bounds__(256) void zk_frame_maps_kernel(
     const double a2 = A * A, b2 = B * B;
     if (abs_out != nullptr && live && n <= prm.plan_nmax)
       abs_out[Z::complex_index(n, am) * plane + pix] = __builtin_sqrt(a2 + b2);
-    if (!((prm.unselect_mask >> am) & 1)) {
-      const double e2 = a2 + b2;
-      norm2 += e2;
-#pragma unroll
-      for (int f = 0; f < ZK_MAX_FOLDS; ++f)
-        if (f < prm.n_folds) rot[f] = __builtin_fma(prm.w[f][am], e2, rot[f]);
-      Cm[am] += a2 - b2;
-      Sm[am] = __builtin_fma(2.0 * A, B, Sm[am]);
-    }
+    Em[am] += a2 + b2;
+    Cm[am] += a2 - b2;
+    Sm[am] = __builtin_fma(2.0 * A, B, Sm[am]);
   };
 
+  // +m and -m of one (n, |m|) are produced back to back (they live in partner parity classes of the T
+  // product) and folded into the running sums at once, so no moment outlives its own combine().
   const ZK_CONST double* tb = zk_const(tmat);
-  constexpr int KEEP = Z::EE > Z::OE ? Z::EE : Z::OE;
-  double keep[KEEP > 0 ? KEEP : 1];
-  // even m: cos terms (class EE, includes m = 0) then their sin partners (class OO)
-  constexpr int offEE = 0, offOE = Z::EE;  // class-ordered slots: [EE | OE | EO | OO]
-  acc.template transform_class<ZK_EE>(tb, [&](auto slot, double v) { keep[decltype(slot)::value - offEE] = v; });
-  acc.template transform_class<ZK_OO>(tb, [&](auto slot, double v) {
-    constexpr int s = decltype(slot)::value;
-    constexpr int n = Z::slot_n(s), am = -Z::slot_m(s);
-    combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{},
-            keep[Z::slot_of(n, am) - offEE], v);
-  });
-  // m = 0 has no partner
   zk_for_each_int(
-      [&](auto i) {
-        constexpr int n = 2 * decltype(i)::value;
-        combine(std::integral_constant<int, n>{}, std::integral_constant<int, 0>{}, keep[Z::slot_of(n, 0) - offEE], 0.0);
+      [&](auto k) {
+        constexpr int n = Z::complex_n(decltype(k)::value), am = Z::complex_m(decltype(k)::value);
+        const double A = acc.template moment<Z::slot_of(n, am)>(tb);
+        double B = 0.0;
+        if constexpr (am > 0) B = acc.template moment<Z::slot_of(n, -am)>(tb);
+        combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
       },
-      std::make_integer_sequence<int, NMAX / 2 + 1>{});
-  // odd m: cos terms (class OE) then their sin partners (class EO)
-  acc.template transform_class<ZK_OE>(tb, [&](auto slot, double v) { keep[decltype(slot)::value - offOE] = v; });
-  acc.template transform_class<ZK_EO>(tb, [&](auto slot, double v) {
-    constexpr int s = decltype(slot)::value;
-    constexpr int n = Z::slot_n(s), am = -Z::slot_m(s);
-    combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{},
-            keep[Z::slot_of(n, am) - offOE], v);
-  });
+      std::make_integer_sequence<int, Z::NC>{});
 
-  const double inv = prm.normalize ? 1.0 / norm2 : 1.0;  // 0/0 -> NaN exactly where NumPy gives NaN
-  if (rot_out != nullptr && live) {
+  // drop the unselected |m| (wave-uniform mask), then the per-pixel scalar ||Z_sel||^2
+  double norm2 = 0.0;
 #pragma unroll
-    for (int f = 0; f < ZK_MAX_FOLDS; ++f)
-      if (f < prm.n_folds) rot_out[f * plane + pix] = rot[f] * inv;
+  for (int m = 0; m <= NMAX; ++m) {
+    const double keep_m = ((prm.unselect_mask >> m) & 1) ? 0.0 : 1.0;
+    Em[m] *= keep_m;
+    Cm[m] *= keep_m;
+    Sm[m] *= keep_m;
+    norm2 += Em[m];
+  }
+  const double inv = prm.normalize ? 1.0 / norm2 : 1.0;  // 0/0 -> NaN exactly where NumPy gives NaN
+  // table layout: [ZK_MAX_FOLDS][ZK_SEP_ROW] fold weights by |m|, then [rows][2][ZK_SEP_ROW] cos / sin(m theta)
+  const ZK_CONST double* wtab = zk_const(trig);
+  if (rot_out != nullptr) {
+    for (int f = 0; f < prm.n_folds; ++f) {
+      double r = 0.0;
+#pragma unroll
+      for (int m = 0; m <= NMAX; ++m) r = __builtin_fma(wtab[f * ZK_SEP_ROW + m], Em[m], r);
+      if (live) rot_out[f * plane + pix] = r * inv;
+    }
   }
   if (mirror_out != nullptr) {
-    const ZK_CONST double* cs = zk_const(trig);  // [n_theta][2][ZK_SEP_ROW]: cos(m theta), sin(m theta)
+    const ZK_CONST double* cs = wtab + ZK_MAX_FOLDS * ZK_SEP_ROW;
     double best = -__builtin_inf();
-    for (int i = 0; i < prm.n_theta; ++i) {
-      double s = 0.0;
+    auto take = [&](double s) { best = s > best || s != s ? s : best; };  // NaN propagates like numpy.max
+    if (prm.theta_sym) {
+      // Uniform full-circle grid: theta, pi - theta, pi + theta and 2 pi - theta are all grid points and
+      //   cos m(pi -+ t) = (-1)^m cos mt,  sin m(pi - t) = -(-1)^m sin mt,  sin m(pi + t) = (-1)^m sin mt,
+      // so the first quarter of the grid (n_theta/4 + 1 rows) yields all n_theta scores.
+#pragma unroll 2
+      for (int i = 0; i <= prm.n_theta / 4; ++i) {
+        double ce = 0.0, co = 0.0, se = 0.0, so = 0.0;  // C / S parts over even / odd m
 #pragma unroll
-      for (int m = 0; m <= NMAX; ++m) {
-        s = __builtin_fma(Cm[m], cs[(2 * i) * ZK_SEP_ROW + m], s);
-        s = __builtin_fma(Sm[m], cs[(2 * i + 1) * ZK_SEP_ROW + m], s);
+        for (int m = 1; m <= NMAX; ++m) {  // m = 0 is always unselected (C_0 = S_0 = 0)
+          const double c = cs[(2 * i) * ZK_SEP_ROW + m], sn = cs[(2 * i + 1) * ZK_SEP_ROW + m];
+          if (m & 1) {
+            co = __builtin_fma(Cm[m], c, co);
+            so = __builtin_fma(Sm[m], sn, so);
+          } else {
+            ce = __builtin_fma(Cm[m], c, ce);
+            se = __builtin_fma(Sm[m], sn, se);
+          }
+        }
+        const double cp = ce + co, cn = ce - co, sp = se + so, sm = se - so;
+        take(cp + sp);  // theta
+        take(cp - sp);  // 2 pi - theta
+        take(cn - sm);  // pi - theta
+        take(cn + sm);  // pi + theta
       }
-      best = s > best || s != s ? s : best;  // NaN propagates like numpy.max
+    } else {
+#pragma unroll 2
+      for (int i = 0; i < prm.n_theta; ++i) {
+        double sc = 0.0;
+#pragma unroll
+        for (int m = 1; m <= NMAX; ++m) {
+          sc = __builtin_fma(Cm[m], cs[(2 * i) * ZK_SEP_ROW + m], sc);
+          sc = __builtin_fma(Sm[m], cs[(2 * i + 1) * ZK_SEP_ROW + m], sc);
+        }
+        take(sc);
+      }
     }
     if (live) mirror_out[pix] = best * inv;
   }
@@ -212,6 +231,8 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
     if (am < 31) prm.unselect_mask |= 1 << am;
   }
   if (!(prm.unselect_mask & 1)) return zk_fail(ZK_E_BADARG, "m=0 must be included in m_unselect.");
+  // device table: fold weights, then the trig rows (see the kernel)
+  std::vector<double> tab((size_t)(ZK_MAX_FOLDS + 2 * (prm.n_theta > 0 ? n_theta : 0)) * ZK_SEP_ROW, 0.0);
   for (int f = 0; f < prm.n_folds; ++f) {
     const int fold = folds[f];
     if (fold <= 0) return zk_fail(ZK_E_BADARG, "folds must be positive");
@@ -222,27 +243,33 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
       if (am <= 1) w = 0.0;
       else if (am % fold == 0) w = 1.0;
       else w = fold > 1 ? -1.0 / (double)(fold - 1) : 0.0;
-      prm.w[f][am] = w;
+      if (am < 31 && ((prm.unselect_mask >> am) & 1)) w = 0.0;  // dropped before the weights apply
+      tab[(size_t)f * ZK_SEP_ROW + am] = w;
     }
   }
   if (prm.n_theta > 0) {
-    std::vector<double> tr((size_t)n_theta * 2 * ZK_SEP_ROW, 0.0);
+    prm.theta_sym = n_theta % 4 == 0;
+    for (int i = 0; i < n_theta && prm.theta_sym; ++i)
+      prm.theta_sym = fabs(theta[i] - 2.0 * M_PI * (double)i / (double)n_theta) <= 1e-12;
+    double* tr = tab.data() + (size_t)ZK_MAX_FOLDS * ZK_SEP_ROW;
     for (int i = 0; i < n_theta; ++i)
       for (int m = 0; m <= knm; ++m) {
         tr[((size_t)2 * i) * ZK_SEP_ROW + m] = cos((double)m * theta[i]);
         tr[((size_t)2 * i + 1) * ZK_SEP_ROW + m] = sin((double)m * theta[i]);
       }
-    zk_sep_tables* t = p->sep;
-    if (t->trig_doubles < tr.size()) {
-      if (t->d_trig) ZK_HIP(hipFree(t->d_trig));
-      t->d_trig = nullptr;
-      ZK_HIP(hipMalloc((void**)&t->d_trig, tr.size() * sizeof(double)));
-      t->trig_doubles = tr.size();
-    }
-    // stream-ordered upload: a previous launch on `s` may still be reading the table
-    ZK_HIP(hipMemcpyAsync(t->d_trig, tr.data(), tr.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    ZK_HIP(hipStreamSynchronize(s));  // tr is a stack-lifetime host buffer
   }
+  zk_sep_tables* t = p->sep;
+  if (t->trig_doubles < tab.size()) {
+    ZK_HIP(hipStreamSynchronize(s));  // a previous launch may still read the old table
+    if (t->d_trig) ZK_HIP(hipFree(t->d_trig));
+    t->d_trig = nullptr;
+    t->trig_doubles = 0;
+    ZK_HIP(hipMalloc((void**)&t->d_trig, tab.size() * sizeof(double)));
+    t->trig_doubles = tab.size();
+  }
+  // stream-ordered upload from a pageable stack-lifetime buffer: synchronise before it goes away
+  ZK_HIP(hipMemcpyAsync(t->d_trig, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  ZK_HIP(hipStreamSynchronize(s));
   if (dtype == ZK_F32)
     return launch_t<float>(p, in, H, W, row0, n_rows, prm, p->sep->d_trig, rot, ab, mirror, s);
   return launch_t<double>(p, in, H, W, row0, n_rows, prm, p->sep->d_trig, rot, ab, mirror, s);

@@ -16,7 +16,7 @@ import numpy as np
 from . import _native
 
 __all__ = ["shard_bounds", "allgather_patch_moments", "allgather_frame_moments",
-           "patch_moments_device", "frame_moments_device"]
+           "patch_moments_device", "frame_moments_device", "frame_maps_device"]
 
 
 def shard_bounds(n_units: int, rank: int, world: int):
@@ -61,6 +61,28 @@ def frame_moments_device(plan: "_native.Plan", image, row0=0, n_rows=None, out=N
     plan.transform_frame_dev(image.data_ptr(), code, h, w, row0, n_rows, out.data_ptr(),
                              _current_stream_ptr(image))
     return out
+
+
+def frame_maps_device(plan: "_native.Plan", image, n_complex, folds=(2, 3, 4, 6), m_unselect=(0, 1), p=2,
+                      theta=None, want_abs=True, row0=0, n_rows=None):
+    """Fused frame -> symmetry maps for output rows ``[row0, row0+n_rows)`` of a CUDA/HIP torch frame.
+    Returns ``(rot, abs, mirror)`` float64 tensors of shapes ``(len(folds), n_rows, W)``,
+    ``(n_complex, n_rows, W)``, ``(n_rows, W)`` (``None`` for outputs not requested).  Row bands of
+    these maps are what the multi-GPU pipeline all-gathers (``allgather_frame_moments`` works on any
+    ``(planes, rows, W)`` tensor): 41 planes instead of the 66 moment planes at n_max = 10."""
+    import torch
+    assert image.is_cuda and image.is_contiguous()
+    code = _native.ZK_F32 if image.dtype == torch.float32 else _native.ZK_F64
+    h, w = image.shape
+    n_rows = h - row0 if n_rows is None else n_rows
+    mk = lambda planes: torch.empty((planes, n_rows, w), dtype=torch.float64, device=image.device)
+    rot = mk(len(folds)) if folds is not None and len(folds) else None
+    ab = mk(n_complex) if want_abs else None
+    mir = torch.empty((n_rows, w), dtype=torch.float64, device=image.device) if theta is not None else None
+    ptr = lambda t: t.data_ptr() if t is not None else 0
+    plan.frame_maps_dev(image.data_ptr(), code, h, w, row0, n_rows, folds, m_unselect, p, theta,
+                        ptr(rot), ptr(ab), ptr(mir), _current_stream_ptr(image))
+    return rot, ab, mir
 
 
 def allgather_patch_moments(local, n_total=None, group=None, out=None):
