@@ -105,6 +105,22 @@ int zk_transform_frame_dev(zk_plan* plan, const void* image_dev, int dtype, int6
                            void* hip_stream);
 
 /*
+ * Moments of the size x size windows at given positions of a frame: the device form of "cut patches at
+ * key points, then transform the batch" (reference features/_keypoint.py:60-78 + _zps.py:146-157)
+ * without materialising the (N, size, size) batch.
+ *   points : (n_points, 2) int32 (x, y) = (column, row); the window is
+ *            image[y - size/2 : y - size/2 + size, x - size/2 : x - size/2 + size]  (pixels outside the
+ *            frame read as zero; the reference's KeyPoints drops such points beforehand)
+ *   out    : (n_points, n_poly) float64
+ * Needs the row-separable tables (any size; n_max <= 10); otherwise fails and the caller gathers the
+ * patches and uses zk_transform_patches.
+ */
+int zk_transform_points(zk_plan* plan, const void* image_host, int dtype, int64_t height, int64_t width,
+                        const int32_t* points_host, int64_t n_points, double* out_host);
+int zk_transform_points_dev(zk_plan* plan, const void* image_dev, int dtype, int64_t height, int64_t width,
+                            const int32_t* points_dev, int64_t n_points, double* out_dev, void* hip_stream);
+
+/*
  * Fused dense pipeline: frame -> per-pixel symmetry maps, without writing the (n_poly, H, W) moments
  * to memory (reference notebook-3 tail: zmoments.to_complex / rot_maps / mirror_map,
  * _zmoments.py:300-316, 420-493).  Any of the three outputs may be NULL.

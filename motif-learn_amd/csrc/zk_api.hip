@@ -351,3 +351,44 @@ extern "C" int zk_frame_maps(zk_plan* p, const void* image_host, int dtype, int6
   ZK_HIP(hipStreamSynchronize(p->stream));
   return 0;
 }
+
+// ------------------------------------------------------------------------------------
+// moments at points
+// ------------------------------------------------------------------------------------
+extern "C" int zk_transform_points_dev(zk_plan* p, const void* image, int dtype, int64_t H, int64_t W,
+                                       const int32_t* points, int64_t n_points, double* out, void* hip_stream) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  int rc = check_dtype(dtype);
+  if (rc) return rc;
+  if (H <= 0 || W <= 0 || H > 0x3fffffff || W > 0x3fffffff) return zk_fail(ZK_E_BADARG, "bad frame shape");
+  if (n_points < 0) return zk_fail(ZK_E_BADARG, "negative point count");
+  if (n_points == 0) return 0;
+  if (!image || !points || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
+  ZK_HIP(hipSetDevice(p->device));
+  return zk_launch_sep_points(p, image, dtype, H, W, points, n_points, out, (hipStream_t)hip_stream);
+}
+
+extern "C" int zk_transform_points(zk_plan* p, const void* image_host, int dtype, int64_t H, int64_t W,
+                                   const int32_t* points_host, int64_t n_points, double* out_host) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  int rc = check_dtype(dtype);
+  if (rc) return rc;
+  if (H <= 0 || W <= 0) return zk_fail(ZK_E_BADARG, "bad frame shape");
+  if (n_points < 0) return zk_fail(ZK_E_BADARG, "negative point count");
+  if (n_points == 0) return 0;
+  if (!image_host || !points_host || !out_host) return zk_fail(ZK_E_BADARG, "null host pointer");
+  ZK_HIP(hipSetDevice(p->device));
+  const size_t img_bytes = (size_t)H * W * elem_size(dtype);
+  const size_t img_pad = (img_bytes + 255) & ~(size_t)255;
+  const size_t pts_bytes = (size_t)n_points * 2 * sizeof(int32_t);
+  const size_t out_bytes = (size_t)n_points * p->n_poly * sizeof(double);
+  if ((rc = ensure(&p->d_in, &p->d_in_bytes, img_pad + pts_bytes))) return rc;
+  if ((rc = ensure((void**)&p->d_out, &p->d_out_bytes, out_bytes))) return rc;
+  int32_t* d_pts = (int32_t*)((char*)p->d_in + img_pad);
+  ZK_HIP(hipMemcpyAsync(p->d_in, image_host, img_bytes, hipMemcpyHostToDevice, p->stream));
+  ZK_HIP(hipMemcpyAsync(d_pts, points_host, pts_bytes, hipMemcpyHostToDevice, p->stream));
+  if ((rc = zk_transform_points_dev(p, p->d_in, dtype, H, W, d_pts, n_points, p->d_out, p->stream))) return rc;
+  ZK_HIP(hipMemcpyAsync(out_host, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
+  ZK_HIP(hipStreamSynchronize(p->stream));
+  return 0;
+}

@@ -36,6 +36,10 @@ SYMBOLS = {
     "zk_transform_frame": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, POINTER(c_double)]),
     "zk_transform_frame_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
                                        c_void_p, c_void_p]),
+    "zk_transform_points": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, POINTER(c_int32), c_int64,
+                                    POINTER(c_double)]),
+    "zk_transform_points_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+                                        c_void_p]),
     "zk_frame_maps": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, POINTER(c_int32), c_int,
                               POINTER(c_int32), c_int, c_int, POINTER(c_double), c_int, c_void_p, c_void_p,
                               c_void_p]),
@@ -183,6 +187,17 @@ class Plan:
         check(self._lib.zk_transform_frame(self._h, image.ctypes.data_as(c_void_p), code, h, w,
                                            out.ctypes.data_as(POINTER(c_double))),
               "zk_transform_frame")
+        return out
+
+    def transform_points(self, image, points):
+        """Moments of the windows at integer (x, y) points of a host frame -> (N, n_poly) float64."""
+        code = dtype_code(image.dtype)
+        h, w = image.shape
+        pts = np.ascontiguousarray(points, dtype=np.int32).reshape(-1, 2)
+        out = np.empty((pts.shape[0], self.n_poly), dtype=np.float64)
+        check(self._lib.zk_transform_points(self._h, image.ctypes.data_as(c_void_p), code, h, w,
+                                            pts.ctypes.data_as(POINTER(c_int32)), pts.shape[0],
+                                            out.ctypes.data_as(POINTER(c_double))), "zk_transform_points")
         return out
 
     def frame_maps(self, image, n_complex, folds=None, m_unselect=(0, 1), p=2, theta=None, want_abs=True):

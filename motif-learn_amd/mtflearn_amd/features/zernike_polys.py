@@ -146,6 +146,33 @@ class ZPs(BaseEstimator, TransformerMixin):
             return self._transform_patches(images)
         raise ValueError("Images must be 2D or 3D array.")
 
+    def transform_at(self, image, points) -> zmoments:
+        """Moments of the ``size`` x ``size`` windows centred on key points of ``image`` (extension).
+
+        Same numbers as ``self.transform(KeyPoints(points, image, size).extract_patches())`` with the
+        reference's ``features/_keypoint.py:60-78`` -- window ``image[y-s1:y+s2, x-s1:x+s2]`` for the
+        rounded point ``(x, y)``, ``s1 = size // 2`` -- but the ``(N, size, size)`` batch is never built:
+        the kernel reads the windows from the frame resident on the GPU.  Pixels outside the frame count
+        as zero (the reference's ``KeyPoints`` drops border points before extracting)."""
+        image = np.asarray(image)
+        if image.ndim != 2:
+            raise ValueError("transform_at needs a 2D image.")
+        pts = np.rint(np.asarray(points, dtype=np.float64)).astype(np.int64).reshape(-1, 2)
+        if pts.shape[0] == 0:
+            return zmoments(np.empty((0, len(self.n))), self.n, self.m, patch_size=self.size)
+        operand = self._device_operand(image)
+        plan = self._device_plan()
+        if plan.has_path(1, _native.dtype_code(operand.dtype), _native.PATH_SEPARABLE) or \
+                plan.has_path(0, _native.dtype_code(operand.dtype), _native.PATH_SEPARABLE):
+            data = plan.transform_points(operand, pts)
+        else:  # shapes without the separable tables: gather on the host, batch kernel on the device
+            s1 = self.size // 2
+            padded = np.pad(operand, self.size)
+            batch = np.stack([padded[y + self.size - s1:y + 2 * self.size - s1,
+                                     x + self.size - s1:x + 2 * self.size - s1] for x, y in pts])
+            data = plan.transform_patches(np.ascontiguousarray(batch))
+        return zmoments(data=data, n=self.n, m=self.m, patch_size=self.size)
+
     def symmetry_maps(self, image, n_folds=(2, 3, 4, 6), p=2, m_unselect=(0, 1), theta=None,
                       abs_moments=True, mirror=True):
         """Frame -> symmetry maps in one fused pass on the GPU (extension; not in the reference API).

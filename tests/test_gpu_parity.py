@@ -116,6 +116,31 @@ def test_frame_tail_pipeline_golden(golden):
     rel_close(np.abs(zm.to_complex().data), np.abs(golden["pp3_complex"]), rtol=1e-8)
 
 
+def test_moments_at_key_points(native, zo):
+    """transform_at == cut the reference's key-point patches (features/_keypoint.py:60-78) + batch path."""
+    rng = np.random.default_rng(5)
+    for n_max, size, dtype in [(8, 32, np.float32), (10, 32, np.float64), (6, 33, np.float32), (5, 16, np.float32),
+                               (12, 64, np.float32)]:
+        z = _zps(n_max, size)
+        frame = rng.random((150, 210)).astype(dtype)
+        margin = size // 2 + 2
+        pts = np.column_stack([rng.uniform(margin, 210 - margin, 500), rng.uniform(margin, 150 - margin, 500)])
+        ipts = np.rint(pts).astype(int)
+        s1, s2 = size // 2, size - size // 2
+        patches = np.array([frame[y - s1:y + s2, x - s1:x + s2] for x, y in ipts])     # reference slicing
+        ref = zo.moments_patches(patches, z.polynomials)
+        got = z.transform_at(frame, pts)
+        assert got.data.shape == ref.shape and got.patch_size == size
+        rel_close(got.data, ref)
+    z = _zps(8, 32)
+    frame = rng.random((64, 64)).astype(np.float32)
+    edge = z.transform_at(frame, [[0, 0], [63, 63], [5, 60]]).data                       # zero padding outside
+    padded = np.pad(frame, 32)
+    refp = np.array([padded[y + 16:y + 48, x + 16:x + 48] for x, y in [(0, 0), (63, 63), (5, 60)]])
+    rel_close(edge, zo.moments_patches(refp, z.polynomials))
+    assert z.transform_at(frame, np.empty((0, 2))).data.shape == (0, 45)
+
+
 def test_fused_symmetry_maps(native, golden, zo):
     """Fused frame -> maps kernel against the reference's tail on the golden frame and against the
     host container composed with the device transform on random frames (all option combinations)."""
