@@ -8,7 +8,7 @@
 
 typedef long double ld;
 
-static const int kSepNmax[] = {4, 6, 8, 10};  // instantiated kernels (zk_sep_frame/patches.hip)
+static const int kSepNmax[] = {4, 6, 8, 10, 12};  // instantiated kernels (12: dense + points kernels only)
 
 // x^a = sum_i L[a][i] P_i(x), from x P_i = ((i+1) P_{i+1} + i P_{i-1}) / (2i+1); all terms positive.
 static std::vector<std::vector<ld>> monomial_to_legendre(int deg) {

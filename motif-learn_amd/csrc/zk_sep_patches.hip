@@ -242,7 +242,7 @@ int launch_run(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
 
 bool zk_sep_patches_available(const zk_plan* p, int dtype) {
   const zk_sep_tables* t = p->sep;
-  return t && dtype == ZK_F32 && t->n_units > 0 && p->n_poly <= 1024;
+  return t && dtype == ZK_F32 && t->n_units > 0 && t->kernel_nmax <= 10 && p->n_poly <= 1024;
 }
 
 int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {

@@ -70,6 +70,7 @@ int launch_t(zk_plan* p, const void* img, const int32_t* pts, int64_t H, int64_t
     case 6: return launch_one<6, T>(p, img, pts, H, W, n_points, out, s);
     case 8: return launch_one<8, T>(p, img, pts, H, W, n_points, out, s);
     case 10: return launch_one<10, T>(p, img, pts, H, W, n_points, out, s);
+    case 12: return launch_one<12, T>(p, img, pts, H, W, n_points, out, s);
   }
   return zk_fail(ZK_E_BADARG, "no point kernel for this n_max");
 }

@@ -120,7 +120,7 @@ def test_moments_at_key_points(native, zo):
     """transform_at == cut the reference's key-point patches (features/_keypoint.py:60-78) + batch path."""
     rng = np.random.default_rng(5)
     for n_max, size, dtype in [(8, 32, np.float32), (10, 32, np.float64), (6, 33, np.float32), (5, 16, np.float32),
-                               (12, 64, np.float32)]:
+                               (12, 64, np.float32), (13, 40, np.float32)]:
         z = _zps(n_max, size)
         frame = rng.random((150, 210)).astype(dtype)
         margin = size // 2 + 2
@@ -131,7 +131,7 @@ def test_moments_at_key_points(native, zo):
         ref = zo.moments_patches(patches, z.polynomials)
         got = z.transform_at(frame, pts)
         assert got.data.shape == ref.shape and got.patch_size == size
-        rel_close(got.data, ref)
+        rel_close(got.data, ref, atol_scale=1e-11 if n_max > 10 else 1e-12)
     z = _zps(8, 32)
     frame = rng.random((64, 64)).astype(np.float32)
     edge = z.transform_at(frame, [[0, 0], [63, 63], [5, 60]]).data                       # zero padding outside
@@ -224,8 +224,9 @@ def test_frame_shapes_vs_oracle(native, zo, n_max, size, shape, dtype):
     z = _zps(n_max, size)
     img = (rng.random(shape) - 0.5).astype(dtype)
     ref = zo.moments_frame_direct(img, z.polynomials)
-    for got in _both_paths(native, z, img, 1).values():
-        rel_close(got, ref)
+    for name, got in _both_paths(native, z, img, 1).items():
+        # the separable path's T entries grow with n_max: ~1e-12 * max|Z| of rounding at n_max 11-12
+        rel_close(got, ref, atol_scale=1e-11 if (name == "separable" and n_max > 10) else 1e-12)
 
 
 def test_zero_and_constant_inputs(native):
@@ -362,5 +363,5 @@ def test_config3_and_config5_sizes(native, zo):
         ref = np.stack([zo.moments_frame_direct(frame, z.polynomials, rows=[r], cols=[c])[:, 0, 0]
                         for r, c in zip(rows, cols)])
         got = band[:, torch.from_numpy(rows - 1536).to(dev), torch.from_numpy(cols).to(dev)].T.cpu().numpy()
-        rel_close(got, ref)
+        rel_close(got, ref, atol_scale=1e-11 if n_max > 10 else 1e-12)
         del band
