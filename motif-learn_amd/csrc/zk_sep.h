@@ -91,7 +91,7 @@ struct zk_sep_unit {    // batch kernel: 16 quadrant pixels of one row pair (see
   int32_t c0;           // first quadrant column of the unit
   int32_t cmin;         // first quadrant column of this ROW inside the disk
   int32_t r;            // row index (selects the y table row)
-  int32_t row_end;      // 1: the row pair is complete after this unit
+  int32_t row_end;      // bit 0: the row pair is complete after this unit; bits 8..: cmax = ceil(K/2)
 };
 
 struct zk_sep_tables {
@@ -107,7 +107,7 @@ struct zk_sep_tables {
   int tile_pitch = 0;
   double* d_trig = nullptr;        // fused maps: [n_theta][2][ZK_SEP_ROW] cos / sin(m theta), per call
   size_t trig_doubles = 0;
-  // batch kernel (float32, K % 32 == 0)
+  // batch kernel (float32, K % 4 == 0, K >= 16)
   int run = 0;
   int n_units = 0;
   zk_sep_unit* d_units = nullptr;

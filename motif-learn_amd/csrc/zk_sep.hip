@@ -199,13 +199,17 @@ int zk_sep_build(zk_plan* p, const double* basis) {
   t->n_rows = (int)rows.size();
   if ((rc = upload(&t->d_rows, rows))) return rc;
 
-  if (K % 32 == 0) {  // batch kernel: every quadrant row splits into whole 16-pixel units
+  if (K % 4 == 0 && K >= 16) {  // batch kernel: patch rows are whole 16-B granules
+    // A unit is 16 quadrant columns c0..c0+15 of one row pair, fetched as 64-B runs: (r, c0..c0+15) and
+    // its column mirror (r, K-16-c0..K-1-c0), same for row K-1-r; at K == 32 the two runs of a row are
+    // the two halves of one 128-B line and are fetched as one run (RUN = 8).  Columns >= Q of the last
+    // unit of a row belong to the mirrored half and are masked by cmax.
     t->run = (K == 32) ? 8 : 4;
     std::vector<zk_sep_unit> units;
     for (const zk_sep_row& row : rows) {
       const int r = row.r, rm = K - 1 - r;
       const size_t first = units.size();
-      for (int c0 = 0; c0 + 16 <= K / 2; c0 += 16) {
+      for (int c0 = 0; c0 < Q; c0 += 16) {
         if (c0 + 16 <= row.cmin) continue;  // unit entirely outside the disk
         zk_sep_unit u = {};
         if (t->run == 8) {
@@ -220,9 +224,10 @@ int zk_sep_build(zk_plan* p, const double* basis) {
         u.c0 = c0;
         u.cmin = row.cmin;
         u.r = r;
+        u.row_end = Q << 8;  // bits 8..: cmax (first column that is not a quadrant column); bit 0: row end
         units.push_back(u);
       }
-      if (units.size() > first) units.back().row_end = 1;
+      if (units.size() > first) units.back().row_end |= 1;
     }
     t->n_units = (int)units.size();
     if ((rc = upload(&t->d_units, units))) return rc;

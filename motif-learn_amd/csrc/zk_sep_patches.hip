@@ -1,5 +1,5 @@
 // zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157) for float32
-// patches: HBM-streaming, LDS-DMA transposed, row-separable arithmetic.
+// patches of any size K % 4 == 0, K >= 16: HBM-streaming, LDS-DMA transposed, row-separable arithmetic.
 //
 // Work decomposition.  One wave owns 64 consecutive patches, one patch per lane, and keeps that
 // patch's accumulators in VGPRs for the whole patch, so every multiplier that is not a pixel is
@@ -7,7 +7,7 @@
 // cross-lane reduction).  HBM holds a patch contiguously while a lane needs "pixel t of my patch";
 // that transposition is done by the LDS-DMA engine:
 //
-//   unit    = 16 quadrant pixels of one row pair (r, K-1-r) for all 64 patches = 16 KiB.
+//   unit    = 16 quadrant columns of one row pair (r, K-1-r) for all 64 patches = 16 KiB.
 //   stage   = 16 global_load_lds_dwordx4; each instruction moves whole 128-B (RUN=8, K=32) or 64-B
 //             (RUN=4) runs of 8 / 16 patches, so HBM and the TCP see full-line requests (measured:
 //             6.1 TB/s for this access pattern alone, profiles/r01_micro_sfma.txt).  The LDS image is
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
   issue(0);
 #endif
   for (int u = 0; u < n_units; ++u) {
-    const int c0 = utab[8 * u + 4], cmin = utab[8 * u + 5], r = utab[8 * u + 6], rend = utab[8 * u + 7];
+    const int c0 = utab[8 * u + 4], cmin = utab[8 * u + 5], r = utab[8 * u + 6];
+    const int rend = utab[8 * u + 7] & 1, cmax = utab[8 * u + 7] >> 8;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of unit u has landed
     // The unit is consumed in two halves of 8 quadrant pixels so that only 32 staging VGPRs are live:
     // the outer half first (quadrant columns c0..c0+7, often entirely outside the disk and then not even
@@ -156,14 +157,15 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int c = c0 + 4 * (q0 + i) + e;
-          if (c >= cmin)  // wave-uniform: quadrant pixel inside the disk
+          if (c >= cmin && c < cmax)  // wave-uniform: quadrant pixel inside the disk
             acc.pixel((double)A[i][e], (double)B[i][3 - e], (double)C[i][e], (double)D[i][3 - e],
                       px + c * ZK_SEP_ROW);
         }
       }
     };
-    if (cmin < c0 + 8) half(0, false);
-    half(2, true);
+    const bool outer = cmin < c0 + 8, inner = cmax > c0 + 8;  // which halves hold disk pixels
+    if (outer) half(0, !inner);
+    if (inner) half(2, true);
 #if ZK_ABLATE != 1
     if (rend) acc.row_end(px + r * ZK_SEP_ROW);
 #endif

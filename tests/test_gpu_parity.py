@@ -200,6 +200,8 @@ def test_patches_ragged_counts(native, zo, n_patches):
     (10, 64, np.float32),
     (4, 32, np.float32), (5, 32, np.float32), (6, 32, np.float32), (7, 32, np.float32), (9, 48, np.float32),
     (9, 32, np.float32), (1, 32, np.float32), (3, 64, np.float32), (10, 96, np.float32),
+    (8, 16, np.float32), (8, 20, np.float32), (10, 24, np.float32), (6, 28, np.float32), (8, 36, np.float32),
+    (10, 40, np.float32), (10, 72, np.float32), (7, 100, np.float32), (4, 128, np.float32),
     (8, 32, np.float64), (3, 16, np.float32), (6, 33, np.float32), (8, 72, np.float32), (0, 5, np.float64),
     (12, 64, np.float64), (0, 1, np.float32),
 ])

@@ -124,6 +124,21 @@ def test_zps_validation_messages():
     assert empty.data.shape == (0, 15) and empty.data.dtype == np.float64
 
 
+def test_extension_methods_validate_before_touching_the_device():
+    z = ZPs(4, 8)
+    with pytest.raises(ValueError, match="symmetry_maps needs a 2D image."):
+        z.symmetry_maps(np.zeros((2, 8, 8)))
+    with pytest.raises(ValueError, match=r"image size \(7x20\) must be at least"):
+        z.symmetry_maps(np.zeros((7, 20)))
+    with pytest.raises(ValueError, match="m=0 must be included in m_unselect."):
+        z.symmetry_maps(np.zeros((16, 16)), m_unselect=(1, 2))
+    with pytest.raises(ValueError, match="transform_at needs a 2D image."):
+        z.transform_at(np.zeros(8), [[1, 1]])
+    empty = z.transform_at(np.zeros((16, 16)), np.empty((0, 2)))
+    assert empty.data.shape == (0, 15)
+    np.testing.assert_array_equal(z._valid_mask(20, 23), zmoments(np.zeros((15, 20, 23)), z.n, z.m, 8).valid_mask)
+
+
 # ---------------------------------------------------------------- container vs reference vectors
 def test_container_matches_reference(golden):
     z8 = ZPs(8, 32)
