@@ -110,6 +110,8 @@ struct zk_sep_tables {
   // batch kernel (float32, K % 4 == 0, K >= 16)
   int run = 0;
   int n_units = 0;
+  int n_row_starts = 0;            // units that begin a row pair (the unit order may rotate to any of them)
+  int32_t* d_row_starts = nullptr; // [n_row_starts] unit indices
   zk_sep_unit* d_units = nullptr;
 };
 

@@ -69,6 +69,7 @@ void zk_sep_free(zk_plan* p) {
   if (t->d_rows) (void)hipFree(t->d_rows);
   if (t->d_units) (void)hipFree(t->d_units);
   if (t->d_trig) (void)hipFree(t->d_trig);
+  if (t->d_row_starts) (void)hipFree(t->d_row_starts);
   delete t;
   p->sep = nullptr;
 }
@@ -230,7 +231,12 @@ int zk_sep_build(zk_plan* p, const double* basis) {
       if (units.size() > first) units.back().row_end |= 1;
     }
     t->n_units = (int)units.size();
+    std::vector<int32_t> starts;
+    for (size_t k = 0; k < units.size(); ++k)
+      if (k == 0 || (units[k - 1].row_end & 1)) starts.push_back((int32_t)k);
+    t->n_row_starts = (int)starts.size();
     if ((rc = upload(&t->d_units, units))) return rc;
+    if ((rc = upload(&t->d_row_starts, starts))) return rc;
   }
   return 0;
 }

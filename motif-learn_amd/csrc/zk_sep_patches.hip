@@ -48,6 +48,15 @@
 #ifndef ZK_STORE_NT
 #define ZK_STORE_NT 1
 #endif
+// Unit-order rotation.  Waves start together and walk the same unit list, so at any instant nearly all
+// 2048 resident waves would be fetching the SAME row pair of their patches: addresses that agree in bits
+// 7..11, i.e. a fraction of the HBM channels at a time (the kernel time then moves by ~9 % with the
+// buffers' placement, tools/placement.py).  Starting every wave at a different unit spreads the rows in
+// flight over the whole patch period.  A wave starts at the first unit of some row pair, so the units
+// of a row stay consecutive.
+#ifndef ZK_ROTATE
+#define ZK_ROTATE 1
+#endif
 
 namespace {
 
@@ -61,7 +70,8 @@ template <int NMAX, int RUN>
 __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
     const float* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
-    int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp) {
+    int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp, const int32_t* __restrict__ row_starts,
+    int n_row_starts) {
   using S = zk_sep_set<NMAX>;
   constexpr int NRUN = 16 / RUN;        // source runs per unit: 2 lines (RUN=8) or 4 half-lines
   constexpr int PPI = 64 / RUN;         // patches covered by one DMA instruction
@@ -111,10 +121,17 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
   acc.clear_all();
   const ZK_CONST double* px = zk_const(xq);
 
+  // first unit of this wave (see ZK_ROTATE): the start of some row pair; the loop visits off, off+1, ...,
+  // wrapping around, so the units of a row stay consecutive
+  const int off = n_row_starts > 0
+                      ? zk_const(row_starts)[(int)((((long long)blockIdx.x * 4 + wave) * 7) % n_row_starts)]
+                      : 0;
+  auto unit_at = [&](int k) { return k + off < n_units ? k + off : k + off - n_units; };
 #if ZK_ABLATE != 2
-  issue(0);
+  issue(unit_at(0));
 #endif
-  for (int u = 0; u < n_units; ++u) {
+  for (int k = 0; k < n_units; ++k) {
+    const int u = unit_at(k);
     const int c0 = utab[8 * u + 4], cmin = utab[8 * u + 5], r = utab[8 * u + 6];
     const int rend = utab[8 * u + 7] & 1, cmax = utab[8 * u + 7] >> 8;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of unit u has landed
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
       if (rearm) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // unit is in VGPRs: the slab may be re-armed
 #if ZK_ABLATE != 2
-        if (u + 1 < n_units) issue(u + 1);
+        if (k + 1 < n_units) issue(unit_at(k + 1));
 #endif
       }
 #if ZK_ABLATE == 1
@@ -224,7 +241,7 @@ int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
   if (rc) return rc;
   hipLaunchKernelGGL((zk_patch_sep_kernel<NMAX, RUN>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)in,
                      out, t->d_units, t->d_xq, t->d_T, t->d_colmap, t->n_units, p->n_poly, (long long)n_patches,
-                     p->size * p->size * 4, ppp);
+                     p->size * p->size * 4, ppp, t->d_row_starts, ZK_ROTATE ? t->n_row_starts : 0);
   ZK_HIP(hipGetLastError());
   return zk_prof_end(p, s);
 }
