@@ -86,7 +86,7 @@ struct zk_sep_row {     // one quadrant row pair (r, K-1-r) with at least one di
   int32_t cmin;         // first quadrant column inside the disk (columns cmin .. Q-1 are inside)
 };
 
-struct zk_sep_unit {    // batch kernel: 16 quadrant pixels of one row pair (see zk_sep_patches.hip)
+struct zk_sep_unit {    // batch kernel: 16 (float32) / 8 (float64) quadrant columns of one row pair
   int32_t run_off[4];   // byte offsets of the source runs inside a patch
   int32_t c0;           // first quadrant column of the unit
   int32_t cmin;         // first quadrant column of this ROW inside the disk
@@ -107,12 +107,15 @@ struct zk_sep_tables {
   int tile_pitch = 0;
   double* d_trig = nullptr;        // fused maps: [n_theta][2][ZK_SEP_ROW] cos / sin(m theta), per call
   size_t trig_doubles = 0;
-  // batch kernel (float32, K % 4 == 0, K >= 16)
-  int run = 0;
-  int n_units = 0;
-  int n_row_starts = 0;            // units that begin a row pair (the unit order may rotate to any of them)
-  int32_t* d_row_starts = nullptr; // [n_row_starts] unit indices
-  zk_sep_unit* d_units = nullptr;
+  // batch kernel, one unit list per element type ([0] float32: K % 4 == 0, K >= 16; [1] float64: K even, K >= 8)
+  struct batch_tables {
+    int run = 0;                      // granules per source run: 8 (float32, K == 32) or 4
+    int n_units = 0;
+    zk_sep_unit* d_units = nullptr;
+    int n_row_starts = 0;             // units that begin a row pair (the unit order may rotate to any of them)
+    int32_t* d_row_starts = nullptr;  // [n_row_starts] unit indices
+  };
+  batch_tables batch[2];
 };
 
 #ifdef __HIPCC__

@@ -67,9 +67,11 @@ void zk_sep_free(zk_plan* p) {
   if (t->d_T) (void)hipFree(t->d_T);
   if (t->d_colmap) (void)hipFree(t->d_colmap);
   if (t->d_rows) (void)hipFree(t->d_rows);
-  if (t->d_units) (void)hipFree(t->d_units);
+  for (auto& b : t->batch) {
+    if (b.d_units) (void)hipFree(b.d_units);
+    if (b.d_row_starts) (void)hipFree(b.d_row_starts);
+  }
   if (t->d_trig) (void)hipFree(t->d_trig);
-  if (t->d_row_starts) (void)hipFree(t->d_row_starts);
   delete t;
   p->sep = nullptr;
 }
@@ -200,27 +202,32 @@ int zk_sep_build(zk_plan* p, const double* basis) {
   t->n_rows = (int)rows.size();
   if ((rc = upload(&t->d_rows, rows))) return rc;
 
-  if (K % 4 == 0 && K >= 16) {  // batch kernel: patch rows are whole 16-B granules
-    // A unit is 16 quadrant columns c0..c0+15 of one row pair, fetched as 64-B runs: (r, c0..c0+15) and
-    // its column mirror (r, K-16-c0..K-1-c0), same for row K-1-r; at K == 32 the two runs of a row are
-    // the two halves of one 128-B line and are fetched as one run (RUN = 8).  Columns >= Q of the last
-    // unit of a row belong to the mirrored half and are masked by cmax.
-    t->run = (K == 32) ? 8 : 4;
+  // ---- batch kernel unit lists ------------------------------------------------------------------
+  // A unit is UP quadrant columns c0..c0+UP-1 of one row pair (UP = 16 float32 / 8 float64 pixels = 64 B),
+  // fetched as 64-B runs: (r, c0..) and its column mirror (r, K-UP-c0..K-1-c0), same for row K-1-r; for
+  // float32 at K == 32 the two runs of a row are the halves of one 128-B line and are fetched as one run
+  // (RUN = 8).  Columns >= Q of the last unit of a row belong to the mirrored half and are masked by
+  // cmax.  Patch rows must be whole 16-B granules: K % 4 == 0 (float32), K even (float64).
+  for (int dt = 0; dt < 2; ++dt) {
+    const int es = dt == 0 ? 4 : 8, UP = 64 / es;
+    if ((K * es) % 16 != 0 || K < UP) continue;
+    zk_sep_tables::batch_tables& bt = t->batch[dt];
+    bt.run = (dt == 0 && K == 32) ? 8 : 4;
     std::vector<zk_sep_unit> units;
     for (const zk_sep_row& row : rows) {
       const int r = row.r, rm = K - 1 - r;
       const size_t first = units.size();
-      for (int c0 = 0; c0 < Q; c0 += 16) {
-        if (c0 + 16 <= row.cmin) continue;  // unit entirely outside the disk
+      for (int c0 = 0; c0 < Q; c0 += UP) {
+        if (c0 + UP <= row.cmin) continue;  // unit entirely outside the disk
         zk_sep_unit u = {};
-        if (t->run == 8) {
-          u.run_off[0] = r * K * 4;
-          u.run_off[1] = rm * K * 4;
+        if (bt.run == 8) {
+          u.run_off[0] = r * K * es;
+          u.run_off[1] = rm * K * es;
         } else {
-          u.run_off[0] = (r * K + c0) * 4;
-          u.run_off[1] = (r * K + K - 16 - c0) * 4;
-          u.run_off[2] = (rm * K + c0) * 4;
-          u.run_off[3] = (rm * K + K - 16 - c0) * 4;
+          u.run_off[0] = (r * K + c0) * es;
+          u.run_off[1] = (r * K + K - UP - c0) * es;
+          u.run_off[2] = (rm * K + c0) * es;
+          u.run_off[3] = (rm * K + K - UP - c0) * es;
         }
         u.c0 = c0;
         u.cmin = row.cmin;
@@ -230,13 +237,13 @@ int zk_sep_build(zk_plan* p, const double* basis) {
       }
       if (units.size() > first) units.back().row_end |= 1;
     }
-    t->n_units = (int)units.size();
+    bt.n_units = (int)units.size();
     std::vector<int32_t> starts;
     for (size_t k = 0; k < units.size(); ++k)
       if (k == 0 || (units[k - 1].row_end & 1)) starts.push_back((int32_t)k);
-    t->n_row_starts = (int)starts.size();
-    if ((rc = upload(&t->d_units, units))) return rc;
-    if ((rc = upload(&t->d_row_starts, starts))) return rc;
+    bt.n_row_starts = (int)starts.size();
+    if ((rc = upload(&bt.d_units, units))) return rc;
+    if ((rc = upload(&bt.d_row_starts, starts))) return rc;
   }
   return 0;
 }

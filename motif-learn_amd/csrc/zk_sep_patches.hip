@@ -1,5 +1,5 @@
-// zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157) for float32
-// patches of any size K % 4 == 0, K >= 16: HBM-streaming, LDS-DMA transposed, row-separable arithmetic.
+// zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157) for float32 patches
+// (K % 4 == 0, K >= 16) and float64 patches (K even, K >= 8): HBM-streaming, LDS-DMA transposed, row-separable arithmetic.
 //
 // Work decomposition.  One wave owns 64 consecutive patches, one patch per lane, and keeps that
 // patch's accumulators in VGPRs for the whole patch, so every multiplier that is not a pixel is
@@ -66,13 +66,15 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int NMAX, int RUN>
+template <int NMAX, int RUN, typename TIN>
 __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
-    const float* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
+    const TIN* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
     int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp, const int32_t* __restrict__ row_starts,
     int n_row_starts) {
   using S = zk_sep_set<NMAX>;
+  constexpr int PXG = 16 / sizeof(TIN);  // pixels per 16-B granule: 4 (float32) or 2 (float64)
+  typedef TIN gran_t __attribute__((ext_vector_type(PXG)));
   constexpr int NRUN = 16 / RUN;        // source runs per unit: 2 lines (RUN=8) or 4 half-lines
   constexpr int PPI = 64 / RUN;         // patches covered by one DMA instruction
   constexpr int SH = RUN == 8 ? 1 : 2;  // rotation = patch >> SH makes ds_read_b128 conflict-free
@@ -138,11 +140,11 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
     // The unit is consumed in two halves of 8 quadrant pixels so that only 32 staging VGPRs are live:
     // the outer half first (quadrant columns c0..c0+7, often entirely outside the disk and then not even
     // read), then the inner half; the slab is re-armed as soon as the inner half is in registers.
-    auto lds_granule = [&](int rho, int g) -> f32x4 {
-      return *(const f32x4*)(wl + rho * 64 * RUN * 4 + rd[g]);
+    auto lds_granule = [&](int rho, int g) -> gran_t {
+      return *(const gran_t*)(wl + rho * 64 * RUN * 4 + rd[g]);
     };
     auto half = [&](int q0, bool rearm) {  // quadrant granules q0, q0+1 of both rows and their mirrors
-      f32x4 A[2], B[2], C[2], D[2];       // A: (r, q)  B: (r, mirror of q)  C, D: same for row K-1-r
+      gran_t A[2], B[2], C[2], D[2];      // A: (r, q)  B: (r, mirror of q)  C, D: same for row K-1-r
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int q = q0 + i;
@@ -172,15 +174,15 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = c0 + 4 * (q0 + i) + e;
+        for (int e = 0; e < PXG; ++e) {
+          const int c = c0 + PXG * (q0 + i) + e;
           if (c >= cmin && c < cmax)  // wave-uniform: quadrant pixel inside the disk
-            acc.pixel((double)A[i][e], (double)B[i][3 - e], (double)C[i][e], (double)D[i][3 - e],
+            acc.pixel((double)A[i][e], (double)B[i][PXG - 1 - e], (double)C[i][e], (double)D[i][PXG - 1 - e],
                       px + c * ZK_SEP_ROW);
         }
       }
     };
-    const bool outer = cmin < c0 + 8, inner = cmax > c0 + 8;  // which halves hold disk pixels
+    const bool outer = cmin < c0 + 2 * PXG, inner = cmax > c0 + 2 * PXG;  // which halves hold disk pixels
     if (outer) half(0, !inner);
     if (inner) half(2, true);
 #if ZK_ABLATE != 1
@@ -229,9 +231,10 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
   }
 }
 
-template <int NMAX, int RUN>
+template <int NMAX, int RUN, typename TIN>
 int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
   const zk_sep_tables* t = p->sep;
+  const zk_sep_tables::batch_tables& bt = t->batch[sizeof(TIN) == 4 ? 0 : 1];
   const long long waves = (n_patches + 63) / 64;
   const long long blocks = (waves + 3) / 4;
   if (blocks > 0x7fffffffLL) return zk_fail(ZK_E_BADARG, "too many patches for one launch");
@@ -239,20 +242,20 @@ int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
   while (ppp * p->n_poly > 2048) ppp >>= 1;
   int rc = zk_prof_begin(p, s);
   if (rc) return rc;
-  hipLaunchKernelGGL((zk_patch_sep_kernel<NMAX, RUN>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)in,
-                     out, t->d_units, t->d_xq, t->d_T, t->d_colmap, t->n_units, p->n_poly, (long long)n_patches,
-                     p->size * p->size * 4, ppp, t->d_row_starts, ZK_ROTATE ? t->n_row_starts : 0);
+  hipLaunchKernelGGL((zk_patch_sep_kernel<NMAX, RUN, TIN>), dim3((unsigned)blocks), dim3(256), 0, s, (const TIN*)in,
+                     out, bt.d_units, t->d_xq, t->d_T, t->d_colmap, bt.n_units, p->n_poly, (long long)n_patches,
+                     p->size * p->size * (int)sizeof(TIN), ppp, bt.d_row_starts, ZK_ROTATE ? bt.n_row_starts : 0);
   ZK_HIP(hipGetLastError());
   return zk_prof_end(p, s);
 }
 
-template <int RUN>
+template <int RUN, typename TIN>
 int launch_run(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
   switch (p->sep->kernel_nmax) {
-    case 4: return launch_one<4, RUN>(p, in, n_patches, out, s);
-    case 6: return launch_one<6, RUN>(p, in, n_patches, out, s);
-    case 8: return launch_one<8, RUN>(p, in, n_patches, out, s);
-    case 10: return launch_one<10, RUN>(p, in, n_patches, out, s);
+    case 4: return launch_one<4, RUN, TIN>(p, in, n_patches, out, s);
+    case 6: return launch_one<6, RUN, TIN>(p, in, n_patches, out, s);
+    case 8: return launch_one<8, RUN, TIN>(p, in, n_patches, out, s);
+    case 10: return launch_one<10, RUN, TIN>(p, in, n_patches, out, s);
   }
   return zk_fail(ZK_E_BADARG, "no batch kernel for this n_max");
 }
@@ -261,11 +264,13 @@ int launch_run(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
 
 bool zk_sep_patches_available(const zk_plan* p, int dtype) {
   const zk_sep_tables* t = p->sep;
-  return t && dtype == ZK_F32 && t->n_units > 0 && t->kernel_nmax <= 10 && p->n_poly <= 1024;
+  return t && t->batch[dtype == ZK_F32 ? 0 : 1].n_units > 0 && t->kernel_nmax <= 10 && p->n_poly <= 1024;
 }
 
 int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {
   if (((uintptr_t)in & 15) || ((uintptr_t)out & 15))  // 16-B DMA granules and 16-B stores
     return zk_launch_generic_patches(p, in, dtype, n_patches, out, s);
-  return p->sep->run == 8 ? launch_run<8>(p, in, n_patches, out, s) : launch_run<4>(p, in, n_patches, out, s);
+  if (dtype == ZK_F64) return launch_run<4, double>(p, in, n_patches, out, s);
+  return p->sep->batch[0].run == 8 ? launch_run<8, float>(p, in, n_patches, out, s)
+                                   : launch_run<4, float>(p, in, n_patches, out, s);
 }
