@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
   constexpr int NRUN = 16 / RUN;        // source runs per unit: 2 lines (RUN=8) or 4 half-lines
   constexpr int PPI = 64 / RUN;         // patches covered by one DMA instruction
   constexpr int SH = RUN == 8 ? 1 : 2;  // rotation = patch >> SH makes ds_read_b128 conflict-free
+  // nt only where a run is a whole 128-B line: 64-B runs share their line with another unit of the same
+  // row, which must still find it in L2 (default policy: 3.70 -> 2.14 ms at K=16, 8.9 -> 6.0 ms at K=48)
+  constexpr int DMA_AUX = RUN == 8 ? ZK_DMA_AUX : 0;
   __shared__ __attribute__((aligned(16))) float lds[4 * 4096];  // 16 KiB per wave
 
   const int lane = threadIdx.x & 63;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
 #pragma unroll
       for (int pg = 0; pg < RUN; ++pg) {
         __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(wbase + (poff[pg] + ro)),
-                                         ZK_LDS_PTR(wl + (rho * RUN + pg) * 256), 16, 0, ZK_DMA_AUX);
+                                         ZK_LDS_PTR(wl + (rho * RUN + pg) * 256), 16, 0, DMA_AUX);
       }
     }
   };
