@@ -207,10 +207,10 @@ int zk_sep_build(zk_plan* p, const double* basis) {
   // fetched as 64-B runs: (r, c0..) and its column mirror (r, K-UP-c0..K-1-c0), same for row K-1-r; for
   // float32 at K == 32 the two runs of a row are the halves of one 128-B line and are fetched as one run
   // (RUN = 8).  Columns >= Q of the last unit of a row belong to the mirrored half and are masked by
-  // cmax.  Patch rows must be whole 16-B granules: K % 4 == 0 (float32), K even (float64).
+  // cmax.  Any K >= UP works: a run is 64 contiguous bytes of one patch row wherever it starts.
   for (int dt = 0; dt < 2; ++dt) {
     const int es = dt == 0 ? 4 : 8, UP = 64 / es;
-    if ((K * es) % 16 != 0 || K < UP) continue;
+    if (K < UP) continue;  // (rows need not be 16-B aligned: LDS-DMA sources only need element alignment)
     zk_sep_tables::batch_tables& bt = t->batch[dt];
     bt.run = (dt == 0 && K == 32) ? 8 : 4;
     std::vector<zk_sep_unit> units;

@@ -1,5 +1,5 @@
 // zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157) for float32 patches
-// (K % 4 == 0, K >= 16) and float64 patches (K even, K >= 8): HBM-streaming, LDS-DMA transposed, row-separable arithmetic.
+// (K >= 16) and float64 patches (K >= 8), odd K included (LDS-DMA sources only need element alignment): HBM-streaming, LDS-DMA transposed, row-separable arithmetic.
 //
 // Work decomposition.  One wave owns 64 consecutive patches, one patch per lane, and keeps that
 // patch's accumulators in VGPRs for the whole patch, so every multiplier that is not a pixel is
@@ -271,7 +271,7 @@ bool zk_sep_patches_available(const zk_plan* p, int dtype) {
 }
 
 int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {
-  if (((uintptr_t)in & 15) || ((uintptr_t)out & 15))  // 16-B DMA granules and 16-B stores
+  if (((uintptr_t)in & (dtype == ZK_F32 ? 3 : 7)) || ((uintptr_t)out & 15))  // element-aligned DMA, 16-B stores
     return zk_launch_generic_patches(p, in, dtype, n_patches, out, s);
   if (dtype == ZK_F64) return launch_run<4, double>(p, in, n_patches, out, s);
   return p->sep->batch[0].run == 8 ? launch_run<8, float>(p, in, n_patches, out, s)

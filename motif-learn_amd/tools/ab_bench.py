@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--n-max", type=int, default=8)
     ap.add_argument("--rounds", type=int, default=15)
     ap.add_argument("--mode", choices=["patches", "frame"], default="patches")
+    ap.add_argument("--path", type=int, default=0, help="ZK_PATH_* to force (0 auto, 1 generic, 2 folded, 3 separable)")
     args = ap.parse_args()
 
     torch.cuda.set_device(0)
@@ -64,6 +65,8 @@ def main():
         rc = lib.zk_plan_create(K, len(z.n), n32.ctypes.data_as(POINTER(c_int32)), m32.ctypes.data_as(POINTER(c_int32)),
                                 basis.ctypes.data_as(POINTER(c_double)), 0, byref(h))
         assert rc == 0, (path, rc)
+        lib.zk_plan_set_path.argtypes = [c_void_p, c_int]
+        lib.zk_plan_set_path(h, args.path)
         lib.zk_plan_profile(h, 1)
         plans.append((os.path.basename(path), lib, h, []))
 

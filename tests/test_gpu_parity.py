@@ -54,7 +54,7 @@ def _both_paths(native, z, array, mode):
     ("blobs_32", "Z_blobs_8_32", 8, 32, True),
     ("rand_f32_70_32", "Z_rand_f32_8_32", 8, 32, True),
     ("rand_f32_70_32", "Z_rand_f32_10_32", 10, 32, True),
-    ("rand_f64_5_9", "Z_rand_f64_5_9", 5, 9, False),     # odd size: generic kernel only
+    ("rand_f64_5_9", "Z_rand_f64_5_9", 5, 9, True),
     ("rand_f32_6_11", "Z_rand_f32_10_11", 10, 11, False),
     ("rand_f32_3_64", "Z_rand_f32_12_64", 12, 64, False),
 ])
@@ -204,6 +204,8 @@ def test_patches_ragged_counts(native, zo, n_patches):
     (10, 40, np.float32), (10, 72, np.float32), (7, 100, np.float32), (4, 128, np.float32),
     (8, 32, np.float64), (10, 64, np.float64), (6, 8, np.float64), (8, 10, np.float64), (5, 18, np.float64),
     (10, 30, np.float64), (9, 72, np.float64), (8, 34, np.float32), (4, 12, np.float32),
+    (8, 33, np.float32), (6, 17, np.float32), (10, 21, np.float32), (8, 31, np.float32), (10, 65, np.float32),
+    (8, 33, np.float64), (5, 9, np.float64), (7, 15, np.float64), (8, 18, np.float32), (6, 22, np.float32),
     (8, 32, np.float64), (3, 16, np.float32), (6, 33, np.float32), (8, 72, np.float32), (0, 5, np.float64),
     (12, 64, np.float64), (0, 1, np.float32),
 ])
