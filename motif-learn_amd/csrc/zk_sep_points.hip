@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void zk_points_sep_kernel(
   const int Q = (K + 1) / 2;
   for (int ri = 0; ri < n_tab_rows; ++ri) {
     const int r = rtab[2 * ri], cmin = rtab[2 * ri + 1];
+#pragma unroll 2
     for (int c = cmin; c < Q; ++c)
       acc.pixel(px_at(r, c), px_at(r, K - 1 - c), px_at(K - 1 - r, c), px_at(K - 1 - r, K - 1 - c),
                 px + c * ZK_SEP_ROW);
