@@ -37,7 +37,7 @@ __device__ __forceinline__ void zk_for_each_int(F&& f, std::integer_sequence<int
 }
 
 template <int NMAX, typename T>
-__global__ __launch_bounds__(256, (NMAX <= 8 ? 3 : 2)) void zk_frame_maps_kernel(
+__global__ __launch_bounds__(256, (NMAX <= 8 ? 3 : NMAX <= 10 ? 2 : 1)) void zk_frame_maps_kernel(
     const T* __restrict__ img, const zk_sep_row* __restrict__ rows, const double* __restrict__ xq,
     const double* __restrict__ tmat, const double* __restrict__ trig, double* __restrict__ rot_out,
     double* __restrict__ abs_out, double* __restrict__ mirror_out, zk_maps_params prm, int n_tab_rows, int K, int H,
@@ -206,6 +206,7 @@ int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int
     case 6: return launch_one<6, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
     case 8: return launch_one<8, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
     case 10: return launch_one<10, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 12: return launch_one<12, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
   }
   return zk_fail(ZK_E_BADARG, "no fused maps kernel for this n_max");
 }
@@ -215,8 +216,8 @@ int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int
 int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                        const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
                        const double* theta, int n_theta, double* rot, double* ab, double* mirror, hipStream_t s) {
-  if (!zk_sep_frame_available(p, dtype) || p->sep->kernel_nmax > 10)
-    return zk_fail(ZK_E_BADARG, "plan has no fused maps kernel (needs the separable tables and n_max <= 10)");
+  if (!zk_sep_frame_available(p, dtype))
+    return zk_fail(ZK_E_BADARG, "plan has no fused maps kernel (needs the separable tables: n_max <= 12)");
   if (n_folds < 0 || n_folds > ZK_MAX_FOLDS) return zk_fail(ZK_E_BADARG, "at most 8 folds per call");
   if (p_norm != 0 && p_norm != 2) return zk_fail(ZK_E_BADARG, "p must be 2 or 0 (None)");
   if (rot && (!folds || n_folds == 0)) return zk_fail(ZK_E_BADARG, "rot output requested without folds");

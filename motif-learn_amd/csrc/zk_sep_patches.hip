@@ -67,7 +67,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 template <int NMAX, int RUN, typename TIN>
-__global__ __launch_bounds__(256, 2) void zk_patch_sep_kernel(
+__global__ __launch_bounds__(256, (NMAX <= 10 ? 2 : 1)) void zk_patch_sep_kernel(
     const TIN* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
     int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp, const int32_t* __restrict__ row_starts,
@@ -259,6 +259,7 @@ int launch_run(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
     case 6: return launch_one<6, RUN, TIN>(p, in, n_patches, out, s);
     case 8: return launch_one<8, RUN, TIN>(p, in, n_patches, out, s);
     case 10: return launch_one<10, RUN, TIN>(p, in, n_patches, out, s);
+    case 12: return launch_one<12, RUN, TIN>(p, in, n_patches, out, s);
   }
   return zk_fail(ZK_E_BADARG, "no batch kernel for this n_max");
 }
@@ -267,7 +268,7 @@ int launch_run(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
 
 bool zk_sep_patches_available(const zk_plan* p, int dtype) {
   const zk_sep_tables* t = p->sep;
-  return t && t->batch[dtype == ZK_F32 ? 0 : 1].n_units > 0 && t->kernel_nmax <= 10 && p->n_poly <= 1024;
+  return t && t->batch[dtype == ZK_F32 ? 0 : 1].n_units > 0 && p->n_poly <= 1024;
 }
 
 int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {

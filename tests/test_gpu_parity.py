@@ -56,7 +56,7 @@ def _both_paths(native, z, array, mode):
     ("rand_f32_70_32", "Z_rand_f32_10_32", 10, 32, True),
     ("rand_f64_5_9", "Z_rand_f64_5_9", 5, 9, True),
     ("rand_f32_6_11", "Z_rand_f32_10_11", 10, 11, False),
-    ("rand_f32_3_64", "Z_rand_f32_12_64", 12, 64, False),
+    ("rand_f32_3_64", "Z_rand_f32_12_64", 12, 64, True),
 ])
 def test_patches_golden(native, golden, key_in, key_out, n_max, size, expect_fast):
     z = _zps(n_max, size)
@@ -64,7 +64,7 @@ def test_patches_golden(native, golden, key_in, key_out, n_max, size, expect_fas
     assert ("separable" in res) == expect_fast
     for name, got in res.items():
         assert got.dtype == np.float64 and got.shape == golden[key_out].shape
-        rel_close(got, golden[key_out])
+        rel_close(got, golden[key_out], atol_scale=1e-11 if (name == "separable" and n_max > 10) else 1e-12)
 
 
 def test_patches_api_dtypes_and_layouts(golden):
@@ -156,7 +156,8 @@ def test_fused_symmetry_maps(native, golden, zo):
     np.testing.assert_array_equal(maps["abs_m"], zc_m)
     rng = np.random.default_rng(77)
     for n_max, size, shape, dtype in [(8, 32, (70, 90), np.float32), (10, 32, (40, 130), np.float64),
-                                      (5, 16, (33, 65), np.float32), (7, 33, (40, 50), np.float32)]:
+                                      (5, 16, (33, 65), np.float32), (7, 33, (40, 50), np.float32),
+                                      (12, 40, (50, 70), np.float32)]:
         zz = _zps(n_max, size)
         frame = (rng.random(shape) + 0.1).astype(dtype)
         zm = zz.transform(frame)
@@ -206,6 +207,7 @@ def test_patches_ragged_counts(native, zo, n_patches):
     (10, 30, np.float64), (9, 72, np.float64), (8, 34, np.float32), (4, 12, np.float32),
     (8, 33, np.float32), (6, 17, np.float32), (10, 21, np.float32), (8, 31, np.float32), (10, 65, np.float32),
     (8, 33, np.float64), (5, 9, np.float64), (7, 15, np.float64), (8, 18, np.float32), (6, 22, np.float32),
+    (12, 64, np.float32), (11, 32, np.float32), (12, 33, np.float64),
     (8, 32, np.float64), (3, 16, np.float32), (6, 33, np.float32), (8, 72, np.float32), (0, 5, np.float64),
     (12, 64, np.float64), (0, 1, np.float32),
 ])
@@ -214,8 +216,8 @@ def test_patches_shapes_vs_oracle(native, zo, n_max, size, dtype):
     z = _zps(n_max, size)
     p = (rng.random((77, size, size)) - 0.3).astype(dtype)
     ref = zo.moments_patches(p, z.polynomials)
-    for got in _both_paths(native, z, p, 0).values():
-        rel_close(got, ref)
+    for name, got in _both_paths(native, z, p, 0).items():
+        rel_close(got, ref, atol_scale=1e-11 if (name == "separable" and n_max > 10) else 1e-12)
 
 
 @pytest.mark.parametrize("n_max,size,shape,dtype", [
@@ -276,7 +278,7 @@ def test_c_abi_argument_errors(native):
                               z.polynomials.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 99,
                               ctypes.byref(handle)) == -10001                     # bad device index
     with pytest.raises(RuntimeError, match="not available"):
-        big = _zps(12, 64)._device_plan()
+        big = _zps(13, 64)._device_plan()                                          # no fast tables above n_max 12
         big.set_path(native.PATH_SEPARABLE)
         big.transform_patches(np.zeros((2, 64, 64), np.float32))
 
