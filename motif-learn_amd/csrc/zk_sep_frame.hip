@@ -73,6 +73,7 @@ int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, i
   auto kern = zk_frame_sep_kernel<NMAX, T>;
   if (lds > 64 * 1024)
     ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if ((n_rows + 3) / 4 > 65535) return zk_fail(ZK_E_BADARG, "more than 262140 output rows per call: split the row band");
   dim3 grid((unsigned)((W + 63) / 64), (unsigned)((n_rows + 3) / 4));
   int rc = zk_prof_begin(p, s);
   if (rc) return rc;

@@ -283,6 +283,33 @@ def test_c_abi_argument_errors(native):
         big.transform_patches(np.zeros((2, 64, 64), np.float32))
 
 
+def test_plain_c_client(native, zo, tmp_path):
+    """The C ABI from a C program (gcc, no Python in that process): tests/c_abi_check.c."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    z = _zps(8, 32)
+    rng = np.random.default_rng(11)
+    patches = rng.random((130, 32, 32), dtype=np.float32)
+    image = rng.random((50, 70), dtype=np.float32)
+    src, dst, exe = tmp_path / "in.bin", tmp_path / "out.bin", tmp_path / "c_abi_check"
+    with open(src, "wb") as f:
+        np.array([32, 45, 130, 50, 70], np.int32).tofile(f)
+        z.n.astype(np.int32).tofile(f)
+        z.m.astype(np.int32).tofile(f)
+        z.polynomials.tofile(f)
+        patches.tofile(f)
+        image.tofile(f)
+    libdir = os.path.dirname(native.LIB_PATH)
+    subprocess.check_call(["gcc", "-O1", "-o", str(exe), os.path.join(ROOT, "tests", "c_abi_check.c"),
+                           "-I", os.path.join(ROOT, "include"), "-L", libdir, "-lzernike_hip",
+                           f"-Wl,-rpath,{libdir}"])
+    subprocess.check_call([str(exe), str(src), str(dst)])
+    out = np.fromfile(dst)
+    rel_close(out[:130 * 45].reshape(130, 45), zo.moments_patches(patches, z.polynomials))
+    rel_close(out[130 * 45:].reshape(45, 50, 70), zo.moments_frame_direct(image, z.polynomials))
+
+
 # ------------------------------------------------------------------ BASELINE sizes: properties on device
 def _torch():
     import torch
