@@ -283,6 +283,31 @@ def test_c_abi_argument_errors(native):
         big.transform_patches(np.zeros((2, 64, 64), np.float32))
 
 
+def test_size_sweep_fast_paths_agree_with_generic(native):
+    """Every patch size 2..70 (odd and even, both dtypes, several n_max): whatever fast kernels a plan
+    offers must agree with the generic kernel (itself checked against the oracle above) -- exercises the
+    unit / row tables of the folded and separable paths at every alignment."""
+    rng = np.random.default_rng(2026)
+    checked = 0
+    for size in range(2, 71):
+        for n_max in sorted({min(size, v) for v in (0, 3, 8, 11)}):
+            z = _zps(n_max, size)
+            for dtype in (np.float32, np.float64):
+                p = (rng.random((67, size, size)) - 0.4).astype(dtype)
+                res = _both_paths(native, z, p, 0)
+                img = (rng.random((size + 3, size + 66)) - 0.4).astype(dtype)
+                resf = _both_paths(native, z, img, 1)
+                for out in (res, resf):
+                    ref = out["generic"]
+                    scale = np.abs(ref).max()
+                    for name, got in out.items():
+                        if name != "generic":
+                            tol = (1e-11 if n_max > 10 else 1e-12) * scale
+                            assert np.abs(got - ref).max() <= tol, (size, n_max, dtype, name)
+                            checked += 1
+    assert checked > 500
+
+
 def test_plain_c_client(native, zo, tmp_path):
     """The C ABI from a C program (gcc, no Python in that process): tests/c_abi_check.c."""
     import os
