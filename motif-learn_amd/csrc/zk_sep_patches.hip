@@ -1,5 +1,6 @@
-// zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157) for float32 patches
-// (K >= 16) and float64 patches (K >= 8), odd K included (LDS-DMA sources only need element alignment): HBM-streaming, LDS-DMA transposed, row-separable arithmetic.
+// zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157): HBM-streaming,
+// LDS-DMA transposed, row-separable arithmetic.  float32 patches of any size K >= 16 and float64 patches
+// of any size K >= 8, odd sizes included (LDS-DMA sources only need element alignment); n_max <= 12.
 //
 // Work decomposition.  One wave owns 64 consecutive patches, one patch per lane, and keeps that
 // patch's accumulators in VGPRs for the whole patch, so every multiplier that is not a pixel is
@@ -7,29 +8,33 @@
 // cross-lane reduction).  HBM holds a patch contiguously while a lane needs "pixel t of my patch";
 // that transposition is done by the LDS-DMA engine:
 //
-//   unit    = 16 quadrant columns of one row pair (r, K-1-r) for all 64 patches = 16 KiB.
-//   stage   = 16 global_load_lds_dwordx4; each instruction moves whole 128-B (RUN=8, K=32) or 64-B
-//             (RUN=4) runs of 8 / 16 patches, so HBM and the TCP see full-line requests (measured:
-//             6.1 TB/s for this access pattern alone, profiles/r01_micro_sfma.txt).  The LDS image is
-//             lane-linear per instruction; the granule a lane fetches is rotated by its patch index so
-//             that the later per-lane ds_read_b128 (lane = patch) is bank-conflict-free.
-//   consume = 16 ds_read_b128 pull the unit into 64 VGPRs, the wave immediately re-arms its LDS slab
-//             with the DMA of the next unit and computes from registers while that DMA is in flight.
+//   unit    = 64 B of quadrant columns (16 float32 / 8 float64) of one row pair (r, K-1-r) and their
+//             column mirrors, for all 64 patches = 16 KiB.
+//   stage   = 16 global_load_lds_dwordx4; each instruction moves whole 128-B rows of 8 patches (RUN=8:
+//             float32, K=32) or 64-B runs of 16 patches (RUN=4), so HBM and the TCP see full-line
+//             requests (measured: 6.1 TB/s for this access pattern alone, profiles/r01_micro_sfma.txt).
+//             The LDS image is lane-linear per instruction; the granule a lane fetches is rotated by
+//             its patch index so that the later per-lane ds_read_b128 (lane = patch) is
+//             bank-conflict-free.
+//   consume = the unit is pulled into VGPRs in two halves (8 ds_read_b128 each, the outer half only if
+//             it holds disk pixels); once the inner half is in registers the wave re-arms its LDS slab
+//             with the DMA of its next unit and computes while that DMA is in flight.
 //
 // Arithmetic (zk_sep.h): per quadrant pixel 4 v_cvt + 8 v_add_f64 (mirror folds, exact for float32)
 // + 2(n_max+1) v_fma_f64; per row pair N_poly v_fma_f64; one class-blocked T product per patch.
 // The scalar tables (Legendre values, T) total ~7 KiB at (32, 8) and stay in the scalar data cache --
 // the direct folded sum streamed 76 KiB per wave through it and ran scalar-latency-bound
-// (profiles/r01_patch_fold_pmc.txt).
+// (profiles/r01_patch_fold_pmc.txt).  Compute is fully hidden behind the stream
+// (profiles/r01_ablation.txt): the kernel is bound by mixed read/write HBM traffic.
 //
 // No workgroup barrier exists in the kernel: a wave only ever reads LDS bytes it DMA'd itself (ordered
 // by its own s_waitcnt vmcnt(0)); the waves of a workgroup only share the allocation.  Rows fully
 // outside the unit disk (rows 0 and 31 at K=32) are never fetched.
 //
 // Epilogue: moments go through the same LDS slab to become rows of the (N, N_poly) output and are
-// stored as contiguous 16-B-per-lane runs.
+// stored as contiguous 16-B-per-lane non-temporal runs.
 //
-// Roofline: algorithmic bytes K*K*4 + 8*N_poly per patch (4 456 B at (32, 8)); HBM-bound.
+// Roofline: algorithmic bytes K*K*s + 8*N_poly per patch (4 456 B at float32 (32, 8)); HBM-bound.
 #include "zk_sep.h"
 
 // Timing-only ablation builds (make ABLATE=n -> libzernike_hip_ablate<n>.so; outputs are wrong by
@@ -60,7 +65,6 @@
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 #define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
