@@ -272,7 +272,8 @@ int launch_run(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
 
 bool zk_sep_patches_available(const zk_plan* p, int dtype) {
   const zk_sep_tables* t = p->sep;
-  return t && t->batch[dtype == ZK_F32 ? 0 : 1].n_units > 0 && p->n_poly <= 1024;
+  // K <= 1024 keeps the 32-bit byte offsets inside a 64-patch group (63 * K * K * 8 < 2^31)
+  return t && t->batch[dtype == ZK_F32 ? 0 : 1].n_units > 0 && p->n_poly <= 1024 && p->size <= 1024;
 }
 
 int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {

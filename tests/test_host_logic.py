@@ -256,3 +256,52 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
                 assert "zernike_oracle" not in src, f
+
+
+# ---------------------------------------------------------------- randomized cross-check with the oracle
+@pytest.mark.parametrize("seed", range(6))
+def test_container_matches_oracle_on_random_moments(seed):
+    """The product container (features/moments.py) and the oracle (oracle/zernike_oracle.py) are two
+    independent restatements of reference _zmoments.py; on random moments, random label order and random
+    options they must agree to rounding."""
+    from oracle import zernike_oracle as zo
+    rng = np.random.default_rng(seed)
+    n_max = int(rng.integers(2, 9))
+    n = np.array([a for a in range(n_max + 1) for _ in range(-a, a + 1, 2)])
+    m = np.array([b for a in range(n_max + 1) for b in range(-a, a + 1, 2)])
+    perm = rng.permutation(len(n))                       # labels arrive unsorted
+    shape = (7, len(n)) if seed % 2 == 0 else (len(n), 5, 6)
+    data = rng.standard_normal(shape)
+    axis = 1 if data.ndim == 2 else 0
+    zm = zmoments(np.take(data, perm, axis=axis), n[perm], m[perm], patch_size=9)
+    sd, sn, sm = zo.sort_by_nm(np.take(data, perm, axis=axis), n[perm], m[perm])
+    np.testing.assert_array_equal(zm.data, sd)
+    np.testing.assert_array_equal(zm.n, sn)
+    np.testing.assert_array_equal(zm.m, sm)
+    np.testing.assert_array_equal(zm.data, data)         # canonical order restored
+
+    zc, nc, mc = zo.to_complex(data, n, m)
+    got = zm.to_complex()
+    np.testing.assert_allclose(got.data, zc, rtol=1e-14)
+    np.testing.assert_array_equal(got.n, nc)
+    np.testing.assert_array_equal(got.m, mc)
+    np.testing.assert_allclose(got.to_real().data, data, rtol=1e-14, atol=1e-15)
+
+    folds = sorted(set(int(v) for v in rng.integers(1, 8, size=3)))
+    unsel = (0, 1) if seed % 3 else (0, 1, 2)
+    p = [2, None, 1][seed % 3]
+    np.testing.assert_allclose(zm.rot_maps(folds, p=p, m_unselect=unsel),
+                               zo.rot_maps(data, n, m, folds, p=p, m_unselect=unsel), rtol=1e-12, atol=1e-14)
+    theta = np.linspace(0, 2 * np.pi, 24, endpoint=False) if seed % 2 else None
+    np.testing.assert_allclose(zm.mirror_map(theta=theta, p=p, m_unselect=unsel),
+                               zo.mirror_map(data, n, m, theta=theta, p=p, m_unselect=unsel), rtol=1e-12, atol=1e-14)
+    ang = float(rng.uniform(-180, 180))
+    np.testing.assert_allclose(zm.rotate(ang).data, zo.rotate(data, n, m, ang)[0], rtol=1e-13, atol=1e-15)
+    pick = [int(v) for v in rng.integers(-n_max, n_max + 1, size=2)]
+    sel = zm.select(pick)
+    d2, n2, m2 = zo.select(data, n, m, pick)
+    np.testing.assert_array_equal(sel.data, d2)
+    np.testing.assert_array_equal(sel.m, m2)
+    np.testing.assert_allclose(zm.normalize(order=p).data, zo.normalize(data, order=p), rtol=1e-14)
+    if data.ndim == 3:
+        np.testing.assert_array_equal(zm.valid_mask, zo.valid_mask(data.shape[1:], 9))
