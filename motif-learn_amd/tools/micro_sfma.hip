@@ -81,7 +81,9 @@ static void run_sfma(const char* name, const double* d_tab, int steps, int block
 // Each wave (one workgroup) owns `64 patches` = 256 KiB contiguous and pulls it through a
 // 16-KiB LDS buffer in 16 stages.  ROWPAIR: stage s = rows (s, 31-s) of all 64 patches (128-B
 // lines, 4-KiB stride).  CONTIG: stage s = the s-th contiguous 16 KiB.
-template <bool ROWPAIR>
+// HALF: as ROWPAIR, but only the middle 64 B of every 128-B row are requested (lanes fetching granules
+// 2..5): does a partially requested line cost half the HBM traffic?
+template <bool ROWPAIR, bool HALF = false>
 __global__ __launch_bounds__(64) void dma_kernel(const float* __restrict__ in, long long n_groups,
                                                  float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float lds[4096];
@@ -102,8 +104,9 @@ __global__ __launch_bounds__(64) void dma_kernel(const float* __restrict__ in, l
         } else {
           src = base + s * 16384 + i * 1024 + lane * 16;
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + i * 256), 16, 0, 0);
+        if (!HALF || (((src - base) >> 4) & 7) - 2 < 4u)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(lds + i * 256), 16, 0, 0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       sum += lds[lane * 7 + s];
@@ -113,17 +116,17 @@ __global__ __launch_bounds__(64) void dma_kernel(const float* __restrict__ in, l
   out[(size_t)blockIdx.x * 64 + lane] = sum;
 }
 
-template <bool ROWPAIR>
+template <bool ROWPAIR, bool HALF = false>
 static void run_dma(const char* name, const float* d_in, long long n_groups, int blocks, float* d_out) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((dma_kernel<ROWPAIR>), dim3(blocks), dim3(64), 0, 0, d_in, n_groups, d_out);
+  hipLaunchKernelGGL((dma_kernel<ROWPAIR, HALF>), dim3(blocks), dim3(64), 0, 0, d_in, n_groups, d_out);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   const int it = 5;
   for (int k = 0; k < it; ++k)
-    hipLaunchKernelGGL((dma_kernel<ROWPAIR>), dim3(blocks), dim3(64), 0, 0, d_in, n_groups, d_out);
+    hipLaunchKernelGGL((dma_kernel<ROWPAIR, HALF>), dim3(blocks), dim3(64), 0, 0, d_in, n_groups, d_out);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -171,6 +174,7 @@ int main() {
   for (int wpc : {4, 8, 10}) {
     run_dma<false>("contiguous 16 KiB stages", d_in, n_groups, cu * wpc, d_fo);
     run_dma<true>("row pairs (128 B @ 4 KiB stride)", d_in, n_groups, cu * wpc, d_fo);
+    run_dma<true, true>("row pairs, middle 64 B only (GB/s as if whole)", d_in, n_groups, cu * wpc, d_fo);
   }
   return 0;
 }
