@@ -425,3 +425,18 @@ def test_config3_and_config5_sizes(native, zo):
         got = band[:, torch.from_numpy(rows - 1536).to(dev), torch.from_numpy(cols).to(dev)].T.cpu().numpy()
         rel_close(got, ref, atol_scale=1e-11 if n_max > 10 else 1e-12)
         del band
+        if n_max == 10:
+            # config 5 end to end: the fused maps of the same band against the reference's tail
+            # (oracle rot_maps / to_complex / mirror_map) applied to the oracle moments of those pixels
+            from mtflearn_amd.distributed import frame_maps_device
+            theta = np.linspace(0, 2 * np.pi, 360, endpoint=False)
+            n_c = sum(k // 2 + 1 for k in range(n_max + 1))
+            rot, ab, mir = frame_maps_device(z._device_plan(), f, n_c, folds=(2, 3, 4, 6), theta=theta,
+                                             row0=1536, n_rows=1024)
+            ri, ci = torch.from_numpy(rows - 1536).to(dev), torch.from_numpy(cols).to(dev)
+            rel_close(rot[:, ri, ci].T.cpu().numpy(), zo.rot_maps(ref, z.n, z.m, [2, 3, 4, 6]), rtol=1e-8,
+                      atol_scale=1e-11)
+            rel_close(ab[:, ri, ci].T.cpu().numpy(), np.abs(zo.to_complex(ref, z.n, z.m)[0]), rtol=1e-8,
+                      atol_scale=1e-11)
+            rel_close(mir[ri, ci].cpu().numpy(), zo.mirror_map(ref, z.n, z.m), rtol=1e-8, atol_scale=1e-11)
+            del rot, ab, mir
