@@ -19,6 +19,10 @@
 #include "zk_sep.h"
 
 #define ZK_MAX_FOLDS 8
+// waves per SIMD the register allocator is asked to fit (launch bound)
+#ifndef ZK_MAPS_WAVES
+#define ZK_MAPS_WAVES(NMAX) ((NMAX) <= 8 ? 3 : (NMAX) <= 10 ? 2 : 1)
+#endif
 
 struct zk_maps_params {
   int n_folds;
@@ -37,7 +41,7 @@ __device__ __forceinline__ void zk_for_each_int(F&& f, std::integer_sequence<int
 }
 
 template <int NMAX, typename T>
-__global__ __launch_bounds__(256, (NMAX <= 8 ? 3 : NMAX <= 10 ? 2 : 1)) void zk_frame_maps_kernel(
+__global__ __launch_bounds__(256, ZK_MAPS_WAVES(NMAX)) void zk_frame_maps_kernel(
     const T* __restrict__ img, const zk_sep_row* __restrict__ rows, const double* __restrict__ xq,
     const double* __restrict__ tmat, const double* __restrict__ trig, double* __restrict__ rot_out,
     double* __restrict__ abs_out, double* __restrict__ mirror_out, zk_maps_params prm, int n_tab_rows, int K, int H,
@@ -126,7 +130,9 @@ __global__ __launch_bounds__(256, (NMAX <= 8 ? 3 : NMAX <= 10 ? 2 : 1)) void zk_
     norm2 += Em[m];
   }
   const double inv = prm.normalize ? 1.0 / norm2 : 1.0;  // 0/0 -> NaN exactly where NumPy gives NaN
-  // table layout: [ZK_MAX_FOLDS][ZK_SEP_ROW] fold weights by |m|, then [rows][2][ZK_SEP_ROW] cos / sin(m theta)
+  // table layout: [ZK_MAX_FOLDS][ZK_SEP_ROW] fold weights by |m|, then per angle one compact row
+  // [cos(1 t) .. cos(NMAX t) | sin(1 t) .. sin(NMAX t)] -- 2 NMAX doubles, so the quarter grid of the default
+  // 360 angles (91 rows, 14.6 KB at n_max 10) stays resident in the 16-KiB scalar cache
   const ZK_CONST double* wtab = zk_const(trig);
   if (rot_out != nullptr) {
     for (int f = 0; f < prm.n_folds; ++f) {
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256, (NMAX <= 8 ? 3 : NMAX <= 10 ? 2 : 1)) void zk_
         double ce = 0.0, co = 0.0, se = 0.0, so = 0.0;  // C / S parts over even / odd m
 #pragma unroll
         for (int m = 1; m <= NMAX; ++m) {  // m = 0 is always unselected (C_0 = S_0 = 0)
-          const double c = cs[(2 * i) * ZK_SEP_ROW + m], sn = cs[(2 * i + 1) * ZK_SEP_ROW + m];
+          const double c = cs[i * (2 * NMAX) + m - 1], sn = cs[i * (2 * NMAX) + NMAX + m - 1];
           if (m & 1) {
             co = __builtin_fma(Cm[m], c, co);
             so = __builtin_fma(Sm[m], sn, so);
@@ -170,8 +176,8 @@ __global__ __launch_bounds__(256, (NMAX <= 8 ? 3 : NMAX <= 10 ? 2 : 1)) void zk_
         double sc = 0.0;
 #pragma unroll
         for (int m = 1; m <= NMAX; ++m) {
-          sc = __builtin_fma(Cm[m], cs[(2 * i) * ZK_SEP_ROW + m], sc);
-          sc = __builtin_fma(Sm[m], cs[(2 * i + 1) * ZK_SEP_ROW + m], sc);
+          sc = __builtin_fma(Cm[m], cs[i * (2 * NMAX) + m - 1], sc);
+          sc = __builtin_fma(Sm[m], cs[i * (2 * NMAX) + NMAX + m - 1], sc);
         }
         take(sc);
       }
@@ -236,7 +242,7 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
   }
   if (!(prm.unselect_mask & 1)) return zk_fail(ZK_E_BADARG, "m=0 must be included in m_unselect.");
   // device table: fold weights, then the trig rows (see the kernel)
-  std::vector<double> tab((size_t)(ZK_MAX_FOLDS + 2 * (prm.n_theta > 0 ? n_theta : 0)) * ZK_SEP_ROW, 0.0);
+  std::vector<double> tab((size_t)ZK_MAX_FOLDS * ZK_SEP_ROW + (size_t)(prm.n_theta > 0 ? n_theta : 0) * 2 * knm + 16, 0.0);
   for (int f = 0; f < prm.n_folds; ++f) {
     const int fold = folds[f];
     if (fold <= 0) return zk_fail(ZK_E_BADARG, "folds must be positive");
@@ -258,8 +264,9 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
     double* tr = tab.data() + (size_t)ZK_MAX_FOLDS * ZK_SEP_ROW;
     for (int i = 0; i < n_theta; ++i)
       for (int m = 0; m <= knm; ++m) {
-        tr[((size_t)2 * i) * ZK_SEP_ROW + m] = cos((double)m * theta[i]);
-        tr[((size_t)2 * i + 1) * ZK_SEP_ROW + m] = sin((double)m * theta[i]);
+        if (m == 0) continue;  // m = 0 is always unselected
+        tr[(size_t)i * 2 * knm + m - 1] = cos((double)m * theta[i]);
+        tr[(size_t)i * 2 * knm + knm + m - 1] = sin((double)m * theta[i]);
       }
   }
   zk_sep_tables* t = p->sep;
