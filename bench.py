@@ -82,14 +82,14 @@ def cpu_baseline(z, frame, size):
 
 
 def cpu_dense_baseline(z, frame):
-    """The reference's dense path (fftconvolve, _zps.py:159-193) on a 512 x 512 crop."""
+    """The reference's dense path (fftconvolve, _zps.py:159-193) on a 1024 x 1024 crop (~2.6 GB RSS)."""
     from oracle import zernike_oracle as zo
-    crop = np.ascontiguousarray(frame[:512, :512])
+    crop = np.ascontiguousarray(frame[:1024, :1024])
     t0 = time.perf_counter()
     zo.moments_frame_fft(crop, z.polynomials, z.n)
     dt = time.perf_counter() - t0
     return {"value": crop.size / dt, "unit": "patches/s", "cores": 1, "kind": "port",
-            "sample": f"oracle moments_frame_fft (scipy fftconvolve, single-threaded) on a 512x512 crop, {dt:.2f} s"}
+            "sample": f"oracle moments_frame_fft (scipy fftconvolve, single-threaded) on a 1024x1024 crop, {dt:.2f} s"}
 
 
 def main():
@@ -250,7 +250,15 @@ def main():
         out_f = frame_moments_device(plan, f_dev)
         torch.cuda.synchronize()
         npx, disk = H * H, plan.disk_pixels
-        dense = {"positions": npx, "bound": "fp64-valu", "kernels": {}}
+        # f64 operations the separable kernel executes per position (zk_sep.h): per quadrant disk pixel
+        # 8 adds + 2(n_max+1) FMAs, per disk row pair N_poly FMAs, one class-blocked T product
+        quad_px = int(np.count_nonzero(z.polynomials[0][:(K + 1) // 2, :(K + 1) // 2]))
+        row_pairs = int(np.any(z.polynomials[0][:(K + 1) // 2] != 0, axis=1).sum())
+        cls = [sum(1 for a in range(args.n_max + 1) for b in range(args.n_max + 1 - a) if (a % 2, b % 2) == pq)
+               for pq in ((0, 0), (1, 0), (0, 1), (1, 1))]
+        sep_flops = quad_px * (8 + 4 * (args.n_max + 1)) + 2 * row_pairs * n_poly + 2 * sum(c * c for c in cls)
+        dense = {"positions": npx, "bound": "fp64-valu", "fp64_vector_peak_TFLOPs": FP64_VECTOR_PEAK_TF,
+                 "kernels": {}}
         for path in (_native.PATH_SEPARABLE, _native.PATH_FOLDED):
             if not plan.has_path(1, _native.ZK_F32, path):
                 continue
@@ -269,6 +277,10 @@ def main():
                 "hbm_GBps_algorithmic": npx * (4 + 8 * n_poly) / (fms * 1e-3) / 1e9,
                 "hbm_frac": npx * (4 + 8 * n_poly) / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "fp64_TFLOPs_direct_equiv": npx * 2.0 * disk * n_poly / (fms * 1e-3) / 1e12}
+            if path == _native.PATH_SEPARABLE:
+                ex = npx * sep_flops / (fms * 1e-3) / 1e12
+                dense["kernels"]["separable"].update({"fp64_TFLOPs_executed": ex,
+                                                      "fp64_frac_of_peak": ex / FP64_VECTOR_PEAK_TF})
         plan.set_path(_native.PATH_AUTO)
         result["dense_frame"] = dense
         del out_f
