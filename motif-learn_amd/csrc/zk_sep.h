@@ -213,4 +213,30 @@ struct zk_sep_acc {
     transform_class<ZK_OO>(tmat, emit);
   }
 };
+
+// One row pair of the dense kernels: quadrant columns cmin..Q-1 of the LDS-resident window rows `top`
+// (row r) and `bot` (row K-1-r).  Two pixels per iteration through four running pointers, so the loop
+// spends 4 integer adds per 2 pixels on addressing and the second pixel's LDS reads and scalar row
+// overlap the first pixel's FMAs.
+template <int NMAX>
+__device__ __forceinline__ void zk_sep_row_pair(zk_sep_acc<NMAX>& acc, const double* __restrict__ top,
+                                                const double* __restrict__ bot, int cmin, int Q, int K,
+                                                const ZK_CONST double* px) {
+  const double* tf = top + cmin;
+  const double* tb = top + (K - 1 - cmin);
+  const double* bf = bot + cmin;
+  const double* bb = bot + (K - 1 - cmin);
+  const ZK_CONST double* pr = px + cmin * ZK_SEP_ROW;
+  int c = cmin;
+  for (; c + 1 < Q; c += 2) {
+    acc.pixel(tf[0], tb[0], bf[0], bb[0], pr);
+    acc.pixel(tf[1], tb[-1], bf[1], bb[-1], pr + ZK_SEP_ROW);
+    tf += 2;
+    tb -= 2;
+    bf += 2;
+    bb -= 2;
+    pr += 2 * ZK_SEP_ROW;
+  }
+  if (c < Q) acc.pixel(tf[0], tb[0], bf[0], bb[0], pr);
+}
 #endif

@@ -47,9 +47,7 @@ __global__ __launch_bounds__(256) void zk_frame_sep_kernel(
     const int r = rtab[2 * ri], cmin = rtab[2 * ri + 1];
     const double* __restrict__ top = mine + r * tile_pitch;
     const double* __restrict__ bot = mine + (K - 1 - r) * tile_pitch;
-#pragma unroll 2  // two pixels in flight: the second one's LDS reads and scalar row overlap the first one's FMAs (-7 %)
-    for (int c = cmin; c < Q; ++c)
-      acc.pixel(top[c], top[K - 1 - c], bot[c], bot[K - 1 - c], px + c * ZK_SEP_ROW);
+    zk_sep_row_pair<NMAX>(acc, top, bot, cmin, Q, K, px);
     acc.row_end(px + r * ZK_SEP_ROW);
   }
 
