@@ -16,7 +16,8 @@ import numpy as np
 from . import _native
 
 __all__ = ["shard_bounds", "allgather_patch_moments", "allgather_frame_moments",
-           "patch_moments_device", "frame_moments_device", "frame_maps_device"]
+           "patch_moments_device", "frame_moments_device", "frame_maps_device",
+           "sharded_patch_moments", "sharded_frame_moments"]
 
 
 def shard_bounds(n_units: int, rank: int, world: int):
@@ -110,3 +111,34 @@ def allgather_frame_moments(local, height=None, group=None):
     dist.all_gather_into_tensor(slab, local.contiguous(), group=group)
     full = slab.view(world, n_poly, rows, width).permute(1, 0, 2, 3).reshape(n_poly, world * rows, width)
     return full if height is None else full[:, :height]
+
+
+def sharded_patch_moments(plan: "_native.Plan", patches, group=None):
+    """Whole-job batch transform on an initialised process group: every rank passes the SAME
+    ``(N, K, K)`` CUDA/HIP tensor (or at least its own block of it), computes the moments of its
+    contiguous block ``shard_bounds(N, rank, world)`` and receives the full ``(N, n_poly)`` matrix from
+    one all-gather.  Returns a float64 tensor on the rank's device."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = patches.shape[0]
+    start, count, padded = shard_bounds(n, rank, world)
+    local = torch.zeros((padded, plan.n_poly), dtype=torch.float64, device=patches.device)
+    if count:
+        patch_moments_device(plan, patches[start:start + count].contiguous(), out=local[:count])
+    return allgather_patch_moments(local, n_total=n, group=group)
+
+
+def sharded_frame_moments(plan: "_native.Plan", image, group=None):
+    """Whole-job dense transform: the frame is replicated (it is small), every rank computes the row band
+    ``shard_bounds(H, rank, world)`` and one all-gather reassembles ``(n_poly, H, W)`` on every rank."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    h, w = image.shape
+    start, count, padded = shard_bounds(h, rank, world)
+    local = torch.zeros((plan.n_poly, padded, w), dtype=torch.float64, device=image.device)
+    if count:
+        band = frame_moments_device(plan, image, row0=start, n_rows=count)
+        local[:, :count] = band
+    return allgather_frame_moments(local, height=h, group=group)

@@ -405,6 +405,30 @@ def test_row_bands_reassemble_full_frame(native):
         assert torch.equal(torch.cat(parts, dim=1), full)
 
 
+def test_sharded_helpers_single_rank_group(native, zo):
+    """The whole-job helpers (shard -> kernel -> one all-gather) on a world-size-1 gloo group on the GPU:
+    same code path as N ranks, checked against the oracle."""
+    torch = _torch()
+    import os
+    import torch.distributed as dist
+    from mtflearn_amd.distributed import sharded_patch_moments, sharded_frame_moments
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        z = _zps(8, 32)
+        plan = z._device_plan()
+        rng = np.random.default_rng(3)
+        p = rng.random((333, 32, 32), dtype=np.float32)
+        got = sharded_patch_moments(plan, torch.from_numpy(p).cuda()).cpu().numpy()
+        rel_close(got, zo.moments_patches(p, z.polynomials))
+        img = rng.random((45, 77), dtype=np.float32)
+        gotf = sharded_frame_moments(plan, torch.from_numpy(img).cuda()).cpu().numpy()
+        rel_close(gotf, zo.moments_frame_direct(img, z.polynomials))
+    finally:
+        dist.destroy_process_group()
+
+
 def test_config3_and_config5_sizes(native, zo):
     """Config 3 (64-px, n_max=12) and config 5 (n_max=10) at 4096 x 4096 would write 12.2 / 8.9 GB;
     here a 1024-row band of the 4096-wide frame exercises the same kernels and grid shapes, checked
