@@ -91,7 +91,8 @@ struct zk_sep_unit {    // batch kernel: 16 (float32) / 8 (float64) quadrant col
   int32_t c0;           // first quadrant column of the unit
   int32_t cmin;         // first quadrant column of this ROW inside the disk
   int32_t r;            // row index (selects the y table row)
-  int32_t row_end;      // bit 0: the row pair is complete after this unit; bits 8..: cmax = ceil(K/2)
+  int32_t row_end;      // bit 0: the row pair is complete after this unit; bit 1 (wide units): this unit
+                        // belongs to the second row (K-1-r) of the pair; bits 8..: cmax = ceil(K/2)
 };
 
 struct zk_sep_tables {
@@ -109,7 +110,8 @@ struct zk_sep_tables {
   size_t trig_doubles = 0;
   // batch kernel, one unit list per element type ([0] float32: K % 4 == 0, K >= 16; [1] float64: K even, K >= 8)
   struct batch_tables {
-    int run = 0;                      // granules per source run: 8 (float32, K == 32) or 4
+    int run = 0;                      // granules per source run: 8 (float32, K == 32 or wide) or 4
+    int wide = 0;                     // 1: row-at-a-time units of 32 quadrant columns (float32, K % 64 == 0)
     int n_units = 0;
     zk_sep_unit* d_units = nullptr;
     int n_row_starts = 0;             // units that begin a row pair (the unit order may rotate to any of them)
@@ -151,6 +153,39 @@ struct zk_sep_acc {
       SOm[i] = __builtin_fma(oo, px[2 * i + 1], SOm[i]);
     }
   }
+  // Row-at-a-time form (wide patches, zk_sep_patches.hip): one pixel a and its column mirror b of a
+  // SINGLE row.  The first row of a pair accumulates into SEp / SOp, the second into SEm / SOm, and
+  // pair_combine() turns them into the sum / difference the row_end() step expects:
+  //   SEp <- X1 + X2 (even b),  SEm <- X1 - X2 (odd b),  same for SO.
+  template <bool FIRST>
+  __device__ __forceinline__ void row_pixel(double a, double b, const ZK_CONST double* px) {
+    const double s = a + b, d = a - b;
+#pragma unroll
+    for (int i = 0; i < S::NE; ++i) {
+      if (FIRST) SEp[i] = __builtin_fma(s, px[2 * i], SEp[i]);
+      else SEm[i] = __builtin_fma(s, px[2 * i], SEm[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < S::NO; ++i) {
+      if (FIRST) SOp[i] = __builtin_fma(d, px[2 * i + 1], SOp[i]);
+      else SOm[i] = __builtin_fma(d, px[2 * i + 1], SOm[i]);
+    }
+  }
+  __device__ __forceinline__ void pair_combine() {
+#pragma unroll
+    for (int i = 0; i < S::NE; ++i) {
+      const double t = SEp[i];
+      SEp[i] = t + SEm[i];
+      SEm[i] = t - SEm[i];
+    }
+#pragma unroll
+    for (int i = 0; i < S::NO; ++i) {
+      const double t = SOp[i];
+      SOp[i] = t + SOm[i];
+      SOm[i] = t - SOm[i];
+    }
+  }
+
   // finished row pair: py = P_*(y_r) row of the y table.  Slots are template parameters so that
   // slot -> (a, b) folds at compile time and every register index is static.
   template <int s>

@@ -214,6 +214,34 @@ int zk_sep_build(zk_plan* p, const double* basis) {
     zk_sep_tables::batch_tables& bt = t->batch[dt];
     bt.run = (dt == 0 && K == 32) ? 8 : 4;
     std::vector<zk_sep_unit> units;
+    const int LW = 128 / es;  // pixels per 128-B line: 32 float32, 16 float64
+    if (K % (2 * LW) == 0) {
+      // Wide patches (float32 K % 64 == 0, float64 K % 32 == 0): the quadrant of a row is a whole number
+      // of 128-B lines, so a unit is one line of quadrant columns of ONE row -- (y, c0..c0+LW-1) -- and
+      // its mirror line, and the two rows of a pair are consumed one after the other
+      // (zk_sep_acc::row_pixel / pair_combine).  Every DMA instruction then moves whole lines, as for
+      // float32 at K == 32.
+      bt.run = 8;
+      bt.wide = 1;
+      for (const zk_sep_row& row : rows) {
+        const size_t first = units.size();
+        for (int second = 0; second < 2; ++second) {
+          const int y = second ? K - 1 - row.r : row.r;
+          for (int c0 = 0; c0 < Q; c0 += LW) {
+            if (c0 + LW <= row.cmin) continue;
+            zk_sep_unit u = {};
+            u.run_off[0] = (y * K + c0) * es;
+            u.run_off[1] = (y * K + K - LW - c0) * es;
+            u.c0 = c0;
+            u.cmin = row.cmin;
+            u.r = row.r;
+            u.row_end = (Q << 8) | (second << 1);
+            units.push_back(u);
+          }
+        }
+        if (units.size() > first) units.back().row_end |= 1;
+      }
+    } else
     for (const zk_sep_row& row : rows) {
       const int r = row.r, rm = K - 1 - r;
       const size_t first = units.size();

@@ -70,7 +70,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int NMAX, int RUN, typename TIN>
+template <int NMAX, int RUN, typename TIN, bool WIDE>
 __global__ __launch_bounds__(256, (NMAX <= 10 ? 2 : 1)) void zk_patch_sep_kernel(
     const TIN* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
@@ -189,12 +189,59 @@ __global__ __launch_bounds__(256, (NMAX <= 10 ? 2 : 1)) void zk_patch_sep_kernel
         }
       }
     };
-    const bool outer = cmin < c0 + 2 * PXG, inner = cmax > c0 + 2 * PXG;  // which halves hold disk pixels
-    if (outer) half(0, !inner);
-    if (inner) half(2, true);
-#if ZK_ABLATE != 1
-    if (rend) acc.row_end(px + r * ZK_SEP_ROW);
+    // wide units: 8 quadrant columns (2 granules of the line + 2 of its mirror line) of a single row
+    auto quarter = [&](int q0, bool rearm, auto first_row) {
+      gran_t A[2], B[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        A[i] = lds_granule(0, q0 + i);
+        B[i] = lds_granule(NRUN - 1, 7 - (q0 + i));
+      }
+      if (rearm) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if ZK_ABLATE != 2
+        if (k + 1 < n_units) issue(unit_at(k + 1));
 #endif
+      }
+#if ZK_ABLATE == 1
+#pragma unroll
+      for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(A[i]), "v"(B[i]));
+      if (false)
+#endif
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < PXG; ++e) {
+          const int c = c0 + PXG * (q0 + i) + e;
+          if (c >= cmin)  // wave-uniform: quadrant pixel inside the disk
+            acc.template row_pixel<decltype(first_row)::value>((double)A[i][e], (double)B[i][PXG - 1 - e],
+                                                               px + c * ZK_SEP_ROW);
+        }
+      }
+    };
+    if constexpr (WIDE) {
+      const bool second = (utab[8 * u + 7] >> 1) & 1;
+#pragma unroll
+      for (int q0 = 0; q0 < 8; q0 += 2) {
+        if (cmin < c0 + PXG * (q0 + 2)) {  // the disk columns of a row are a suffix: quarter 6 always runs
+          if (second) quarter(q0, q0 == 6, std::false_type{});
+          else quarter(q0, q0 == 6, std::true_type{});
+        }
+      }
+#if ZK_ABLATE != 1
+      if (rend) {
+        acc.pair_combine();
+        acc.row_end(px + r * ZK_SEP_ROW);
+      }
+#endif
+    } else {
+      const bool outer = cmin < c0 + 2 * PXG, inner = cmax > c0 + 2 * PXG;  // which halves hold disk pixels
+      if (outer) half(0, !inner);
+      if (inner) half(2, true);
+#if ZK_ABLATE != 1
+      if (rend) acc.row_end(px + r * ZK_SEP_ROW);
+#endif
+    }
   }
 
   // ---- Z = T M, then (patch, column) rows via LDS -> 16-B stores ------------------------------------
@@ -238,7 +285,7 @@ __global__ __launch_bounds__(256, (NMAX <= 10 ? 2 : 1)) void zk_patch_sep_kernel
   }
 }
 
-template <int NMAX, int RUN, typename TIN>
+template <int NMAX, int RUN, typename TIN, bool WIDE>
 int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
   const zk_sep_tables* t = p->sep;
   const zk_sep_tables::batch_tables& bt = t->batch[sizeof(TIN) == 4 ? 0 : 1];
@@ -249,21 +296,21 @@ int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
   while (ppp * p->n_poly > 2048) ppp >>= 1;
   int rc = zk_prof_begin(p, s);
   if (rc) return rc;
-  hipLaunchKernelGGL((zk_patch_sep_kernel<NMAX, RUN, TIN>), dim3((unsigned)blocks), dim3(256), 0, s, (const TIN*)in,
+  hipLaunchKernelGGL((zk_patch_sep_kernel<NMAX, RUN, TIN, WIDE>), dim3((unsigned)blocks), dim3(256), 0, s, (const TIN*)in,
                      out, bt.d_units, t->d_xq, t->d_T, t->d_colmap, bt.n_units, p->n_poly, (long long)n_patches,
                      p->size * p->size * (int)sizeof(TIN), ppp, bt.d_row_starts, ZK_ROTATE ? bt.n_row_starts : 0);
   ZK_HIP(hipGetLastError());
   return zk_prof_end(p, s);
 }
 
-template <int RUN, typename TIN>
+template <int RUN, typename TIN, bool WIDE = false>
 int launch_run(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
   switch (p->sep->kernel_nmax) {
-    case 4: return launch_one<4, RUN, TIN>(p, in, n_patches, out, s);
-    case 6: return launch_one<6, RUN, TIN>(p, in, n_patches, out, s);
-    case 8: return launch_one<8, RUN, TIN>(p, in, n_patches, out, s);
-    case 10: return launch_one<10, RUN, TIN>(p, in, n_patches, out, s);
-    case 12: return launch_one<12, RUN, TIN>(p, in, n_patches, out, s);
+    case 4: return launch_one<4, RUN, TIN, WIDE>(p, in, n_patches, out, s);
+    case 6: return launch_one<6, RUN, TIN, WIDE>(p, in, n_patches, out, s);
+    case 8: return launch_one<8, RUN, TIN, WIDE>(p, in, n_patches, out, s);
+    case 10: return launch_one<10, RUN, TIN, WIDE>(p, in, n_patches, out, s);
+    case 12: return launch_one<12, RUN, TIN, WIDE>(p, in, n_patches, out, s);
   }
   return zk_fail(ZK_E_BADARG, "no batch kernel for this n_max");
 }
@@ -279,7 +326,10 @@ bool zk_sep_patches_available(const zk_plan* p, int dtype) {
 int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {
   if (((uintptr_t)in & (dtype == ZK_F32 ? 3 : 7)) || ((uintptr_t)out & 15))  // element-aligned DMA, 16-B stores
     return zk_launch_generic_patches(p, in, dtype, n_patches, out, s);
-  if (dtype == ZK_F64) return launch_run<4, double>(p, in, n_patches, out, s);
+  if (dtype == ZK_F64)
+    return p->sep->batch[1].wide ? launch_run<8, double, true>(p, in, n_patches, out, s)
+                                 : launch_run<4, double>(p, in, n_patches, out, s);
+  if (p->sep->batch[0].wide) return launch_run<8, float, true>(p, in, n_patches, out, s);
   return p->sep->batch[0].run == 8 ? launch_run<8, float>(p, in, n_patches, out, s)
                                    : launch_run<4, float>(p, in, n_patches, out, s);
 }
