@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--n-max", type=int, default=8)
     ap.add_argument("--rounds", type=int, default=15)
     ap.add_argument("--mode", choices=["patches", "frame"], default="patches")
+    ap.add_argument("--f64", action="store_true", help="float64 operands")
     ap.add_argument("--path", type=int, default=0, help="ZK_PATH_* to force (0 auto, 1 generic, 2 folded, 3 separable)")
     args = ap.parse_args()
 
@@ -41,16 +42,19 @@ def main():
     n32, m32 = z.n.astype(np.int32), z.m.astype(np.int32)
     K, H = args.size, args.frame
     f_dev = torch.from_numpy(honeycomb_frame(H, seed=0)).cuda()
+    if args.f64:
+        f_dev = f_dev.double()
+    code, esz = (1, 8) if args.f64 else (0, 4)
     if args.mode == "patches":
         src = f_dev.unfold(0, K, 1).unfold(1, K, 1).reshape(-1, K, K).contiguous()
         n_units = src.shape[0]
         out = torch.empty((n_units, len(z.n)), dtype=torch.float64, device="cuda")
-        bytes_per_unit = K * K * 4 + 8 * len(z.n)
+        bytes_per_unit = K * K * esz + 8 * len(z.n)
     else:
         src = f_dev
         n_units = H * H
         out = torch.empty((len(z.n), H, H), dtype=torch.float64, device="cuda")
-        bytes_per_unit = 4 + 8 * len(z.n)
+        bytes_per_unit = esz + 8 * len(z.n)
     torch.cuda.synchronize()
 
     plans = []
@@ -72,9 +76,9 @@ def main():
 
     def run(lib, h):
         if args.mode == "patches":
-            rc = lib.zk_transform_patches_dev(h, c_void_p(src.data_ptr()), 0, n_units, c_void_p(out.data_ptr()), None)
+            rc = lib.zk_transform_patches_dev(h, c_void_p(src.data_ptr()), code, n_units, c_void_p(out.data_ptr()), None)
         else:
-            rc = lib.zk_transform_frame_dev(h, c_void_p(src.data_ptr()), 0, H, H, 0, H, c_void_p(out.data_ptr()), None)
+            rc = lib.zk_transform_frame_dev(h, c_void_p(src.data_ptr()), code, H, H, 0, H, c_void_p(out.data_ptr()), None)
         assert rc == 0
 
     for name, lib, h, ts in plans:          # warm-up
