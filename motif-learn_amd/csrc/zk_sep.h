@@ -111,7 +111,8 @@ struct zk_sep_tables {
   // batch kernel, one unit list per element type ([0] float32: K % 4 == 0, K >= 16; [1] float64: K even, K >= 8)
   struct batch_tables {
     int run = 0;                      // granules per source run: 8 (float32, K == 32 or wide) or 4
-    int wide = 0;                     // 1: row-at-a-time units of 32 quadrant columns (float32, K % 64 == 0)
+    int wide = 0;                     // 1: row-at-a-time units of one quadrant line (float32 K % 64 == 0, float64 K % 32 == 0)
+                                      // 2: two-row units (float32 K == 32): 256 contiguous bytes per patch
     int n_units = 0;
     zk_sep_unit* d_units = nullptr;
     int n_row_starts = 0;             // units that begin a row pair (the unit order may rotate to any of them)
@@ -121,17 +122,12 @@ struct zk_sep_tables {
 };
 
 #ifdef __HIPCC__
+// Row sums of one row pair: S(a, parity of b) of zk_sep.h's header comment.
 template <int NMAX>
-struct zk_sep_acc {
+struct zk_sep_rows {
   using S = zk_sep_set<NMAX>;
-  double M[S::NP];
   double SEp[S::NE], SEm[S::NE], SOp[S::NO > 0 ? S::NO : 1], SOm[S::NO > 0 ? S::NO : 1];
 
-  __device__ __forceinline__ void clear_all() {
-#pragma unroll
-    for (int i = 0; i < S::NP; ++i) M[i] = 0.0;
-    clear_row();
-  }
   __device__ __forceinline__ void clear_row() {
 #pragma unroll
     for (int i = 0; i < S::NE; ++i) SEp[i] = SEm[i] = 0.0;
@@ -153,9 +149,9 @@ struct zk_sep_acc {
       SOm[i] = __builtin_fma(oo, px[2 * i + 1], SOm[i]);
     }
   }
-  // Row-at-a-time form (wide patches, zk_sep_patches.hip): one pixel a and its column mirror b of a
-  // SINGLE row.  The first row of a pair accumulates into SEp / SOp, the second into SEm / SOm, and
-  // pair_combine() turns them into the sum / difference the row_end() step expects:
+  // Row-at-a-time form (zk_sep_patches.hip): one pixel a and its column mirror b of a SINGLE row.  The
+  // first row of a pair accumulates into SEp / SOp, the second into SEm / SOm, and pair_combine() turns
+  // them into the sum / difference the row_end() step expects:
   //   SEp <- X1 + X2 (even b),  SEm <- X1 - X2 (odd b),  same for SO.
   template <bool FIRST>
   __device__ __forceinline__ void row_pixel(double a, double b, const ZK_CONST double* px) {
@@ -185,23 +181,39 @@ struct zk_sep_acc {
       SOm[i] = t - SOm[i];
     }
   }
+};
 
-  // finished row pair: py = P_*(y_r) row of the y table.  Slots are template parameters so that
+template <int NMAX>
+struct zk_sep_acc : zk_sep_rows<NMAX> {
+  using S = zk_sep_set<NMAX>;
+  using R = zk_sep_rows<NMAX>;
+  double M[S::NP];
+
+  __device__ __forceinline__ void clear_all() {
+#pragma unroll
+    for (int i = 0; i < S::NP; ++i) M[i] = 0.0;
+    this->clear_row();
+  }
+
+  // finished row pair: py = P_*(y_r) row of the y table; `rs` holds the pair's row sums (this object's
+  // own, or a second set when two row pairs are in flight).  Slots are template parameters so that
   // slot -> (a, b) folds at compile time and every register index is static.
   template <int s>
-  __device__ __forceinline__ void slot_fma(const ZK_CONST double* py) {
+  __device__ __forceinline__ void slot_fma(const R& rs, const ZK_CONST double* py) {
     constexpr int a = S::slot_a(s), b = S::slot_b(s);
-    const double rs = (a & 1) ? ((b & 1) ? SOm[a >> 1] : SOp[a >> 1]) : ((b & 1) ? SEm[a >> 1] : SEp[a >> 1]);
-    M[s] = __builtin_fma(py[b], rs, M[s]);
+    const double v = (a & 1) ? ((b & 1) ? rs.SOm[a >> 1] : rs.SOp[a >> 1])
+                             : ((b & 1) ? rs.SEm[a >> 1] : rs.SEp[a >> 1]);
+    M[s] = __builtin_fma(py[b], v, M[s]);
   }
   template <int... Is>
-  __device__ __forceinline__ void row_all(const ZK_CONST double* py, std::integer_sequence<int, Is...>) {
-    (slot_fma<Is>(py), ...);
+  __device__ __forceinline__ void row_all(const R& rs, const ZK_CONST double* py, std::integer_sequence<int, Is...>) {
+    (slot_fma<Is>(rs, py), ...);
   }
-  __device__ __forceinline__ void row_end(const ZK_CONST double* py) {
-    row_all(py, std::make_integer_sequence<int, S::NP>{});
-    clear_row();
+  __device__ __forceinline__ void row_end_from(R& rs, const ZK_CONST double* py) {
+    row_all(rs, py, std::make_integer_sequence<int, S::NP>{});
+    rs.clear_row();
   }
+  __device__ __forceinline__ void row_end(const ZK_CONST double* py) { row_end_from(*this, py); }
 
   // Z (class-ordered Zernike slots) = T * M, one parity class at a time.  `emit(slot, value)` receives
   // each finished moment; `slot` is a std::integral_constant, so callers can use it both as an int
