@@ -6,7 +6,7 @@
 //     reuse of each scalar (P independent "pixels" per lane), table size (scalar-cache fit).
 //  B. the same loop with register-only operands (the VALU ceiling).
 //  C. HBM read patterns for the batch kernel: LDS-DMA of 128-B rows at a 4-KiB stride (one
-//     patch row per 8 lanes, the row-pair staging of zk_fast_patches) against a plain
+//     patch row per 8 lanes, the row-pair staging of zk_sep_patches.hip) against a plain
 //     contiguous LDS-DMA stream of the same bytes.
 //
 // build: hipcc --offload-arch=gfx950 -O3 -o micro_sfma micro_sfma.hip ; run: ./micro_sfma
