@@ -173,6 +173,37 @@ class ZPs(BaseEstimator, TransformerMixin):
             data = plan.transform_patches(np.ascontiguousarray(batch))
         return zmoments(data=data, n=self.n, m=self.m, patch_size=self.size)
 
+    def transform_grid(self, image, step=1) -> zmoments:
+        """Moments of the un-padded ``size`` x ``size`` windows taken every ``step`` pixels (extension).
+
+        Same numbers as ``self.transform(extract_patches(image, size, step))`` with the reference's strided
+        extractor (``denoise/_denoise_svd.py:15-49``): window origins ``0, step, 2 step, ...`` along each
+        axis plus the last admissible origin ``extent - size`` when the stride does not land on it, windows
+        ordered row-major over (row origin, column origin).  No ``(N, size, size)`` batch is materialised:
+        the windows are read from the frame resident on the GPU (``transform_at``)."""
+        image = np.asarray(image)
+        if image.ndim != 2:
+            raise ValueError("transform_grid needs a 2D image.")
+        height, width = image.shape
+        if height < self.size or width < self.size:
+            raise ValueError(
+                f"For FFT convolution, image size ({height}x{width}) must be at least "
+                f"as large as polynomial size ({self.size}x{self.size})")
+        if step < 1:
+            raise ValueError("step must be a positive integer.")
+
+        def origins(extent):
+            last = extent - self.size
+            idx = np.arange(0, last, step)
+            if idx.size == 0 or idx[-1] != last:
+                idx = np.append(idx, last)
+            return idx
+
+        rows, cols = origins(height), origins(width)
+        half = self.size // 2
+        yy, xx = np.meshgrid(rows + half, cols + half, indexing="ij")
+        return self.transform_at(image, np.column_stack([xx.ravel(), yy.ravel()]))
+
     def symmetry_maps(self, image, n_folds=(2, 3, 4, 6), p=2, m_unselect=(0, 1), theta=None,
                       abs_moments=True, mirror=True):
         """Frame -> symmetry maps in one fused pass on the GPU (extension; not in the reference API).

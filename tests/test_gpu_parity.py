@@ -141,6 +141,27 @@ def test_moments_at_key_points(native, zo):
     assert z.transform_at(frame, np.empty((0, 2))).data.shape == (0, 45)
 
 
+def test_strided_grid_matches_reference_extractor(native, zo):
+    """transform_grid == reference extract_patches(image, size, step) (denoise/_denoise_svd.py:15-49,
+    restated here) followed by the batch transform."""
+    rng = np.random.default_rng(8)
+    for size, n_max, shape, step in [(32, 8, (100, 131), 7), (16, 6, (64, 64), 16), (33, 8, (70, 90), 5),
+                                     (32, 10, (32, 40), 3)]:
+        z = _zps(n_max, size)
+        frame = rng.random(shape).astype(np.float32)
+
+        def starts(extent):
+            last = extent - size
+            idx = np.arange(0, last, step)
+            return idx if idx.size and idx[-1] == last else np.append(idx, last)
+
+        ii, jj = starts(shape[0]), starts(shape[1])
+        patches = np.array([frame[i:i + size, j:j + size] for i in ii for j in jj])
+        got = z.transform_grid(frame, step)
+        assert got.data.shape == (len(ii) * len(jj), len(z.n))
+        rel_close(got.data, zo.moments_patches(patches, z.polynomials))
+
+
 def test_fused_symmetry_maps(native, golden, zo):
     """Fused frame -> maps kernel against the reference's tail on the golden frame and against the
     host container composed with the device transform on random frames (all option combinations)."""
