@@ -47,6 +47,9 @@ extern "C" {
 #define ZK_PATH_GENERIC   1  /* any size / n_max / dtype: unfolded direct summation, ~1e-16 of the definition */
 #define ZK_PATH_FOLDED    2  /* frame only: mirror-folded direct summation (4x fewer FMAs), ~1e-15            */
 #define ZK_PATH_SEPARABLE 3  /* mirror-folded row-separable sums (Legendre products), ~1e-13; fastest       */
+#define ZK_PATH_STREAM    4  /* patches only: row-separable sums over the contiguous pixel stream of a patch,
+                                whole 128-B lines whatever the patch size; AUTO prefers it where the row-pair
+                                kernel of ZK_PATH_SEPARABLE would issue half-line requests */
 
 typedef struct zk_plan zk_plan;
 

@@ -175,13 +175,17 @@ static bool path_available(const zk_plan* p, int mode, int dtype, int path) {
     case ZK_PATH_GENERIC: return true;
     case ZK_PATH_FOLDED: return mode == 1 && zk_fast_frame_available(p, dtype);
     case ZK_PATH_SEPARABLE: return mode == 0 ? zk_sep_patches_available(p, dtype) : zk_sep_frame_available(p, dtype);
+    case ZK_PATH_STREAM: return mode == 0 && zk_sep_stream_available(p, dtype);
   }
   return false;
 }
 
-// ZK_PATH_AUTO: separable, else folded (frame), else generic
+// ZK_PATH_AUTO: separable (batches: its stream form where the plan prefers it), else folded (frame), else generic
 static int resolve_path(const zk_plan* p, int mode, int dtype) {
   if (p->path != ZK_PATH_AUTO) return path_available(p, mode, dtype, p->path) ? p->path : -1;
+  if (mode == 0 && path_available(p, mode, dtype, ZK_PATH_STREAM) &&
+      (zk_sep_stream_preferred(p, dtype) || !path_available(p, mode, dtype, ZK_PATH_SEPARABLE)))
+    return ZK_PATH_STREAM;
   if (path_available(p, mode, dtype, ZK_PATH_SEPARABLE)) return ZK_PATH_SEPARABLE;
   if (path_available(p, mode, dtype, ZK_PATH_FOLDED)) return ZK_PATH_FOLDED;
   return ZK_PATH_GENERIC;
@@ -195,7 +199,7 @@ extern "C" int zk_plan_has_path(const zk_plan* p, int mode, int dtype, int path)
 extern "C" int zk_plan_disk_pixels(const zk_plan* p) { return p ? p->npx : 0; }
 
 extern "C" int zk_plan_set_path(zk_plan* p, int path) {
-  if (!p || path < ZK_PATH_AUTO || path > ZK_PATH_SEPARABLE) return zk_fail(ZK_E_BADARG, "bad path");
+  if (!p || path < ZK_PATH_AUTO || path > ZK_PATH_STREAM) return zk_fail(ZK_E_BADARG, "bad path");
   p->path = path;
   return 0;
 }
@@ -223,6 +227,7 @@ extern "C" int zk_transform_patches_dev(zk_plan* p, const void* patches, int dty
   const int path = resolve_path(p, 0, dtype);
   if (path < 0) return zk_fail(ZK_E_BADARG, "the forced kernel path is not available for this plan / dtype");
   if (path == ZK_PATH_SEPARABLE) return zk_launch_sep_patches(p, patches, dtype, n_patches, out, s);
+  if (path == ZK_PATH_STREAM) return zk_launch_sep_stream(p, patches, dtype, n_patches, out, s);
   return zk_launch_generic_patches(p, patches, dtype, n_patches, out, s);
 }
 

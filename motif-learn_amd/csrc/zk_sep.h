@@ -95,6 +95,21 @@ struct zk_sep_unit {    // batch kernel: 16 (float32) / 8 (float64) quadrant col
                         // belongs to the second row (K-1-r) of the pair; bits 8..: cmax = ceil(K/2)
 };
 
+// Stream ("flat") batch kernel, zk_sep_stream.hip: a patch is read as the contiguous pixel stream it is
+// in memory, one 128-B line per unit, whatever K is.
+struct zk_stream_row {  // one patch row with disk pixels, in flat pixel indices t = r * K + c
+  int32_t ts, te;       // first / last (inclusive) disk pixel of the row
+  int32_t r;            // row index (selects the y table row); column of pixel t is t - r * K
+  int32_t pad;
+};
+
+struct zk_stream_unit { // one 128-B line of the patch stream that holds at least one disk pixel
+  int32_t byte_off;     // line offset inside the patch (multiple of 128)
+  int32_t t0;           // flat index of the line's first pixel
+  int32_t row_i;        // first entry of the row table with te >= t0
+  int32_t clamp;        // 1: the line crosses the end of the patch (source offsets are clamped)
+};
+
 struct zk_sep_tables {
   int kernel_nmax = -1;
   int np_kernel = 0;
@@ -119,7 +134,35 @@ struct zk_sep_tables {
     int32_t* d_row_starts = nullptr;  // [n_row_starts] unit indices
   };
   batch_tables batch[2];
+  // stream batch kernel: full-width Legendre table + row / line lists per element type
+  double* d_pfull = nullptr;          // [K + 1][ZK_SEP_ROW] P_a(x_c) for all K columns; row K is zero
+  struct stream_tables {
+    int n_units = 0;
+    zk_stream_unit* d_units = nullptr;
+    int n_rows = 0;                   // without the sentinel entry that closes the table
+    zk_stream_row* d_rows = nullptr;
+    int aligned = 0;                  // patches start on 128-B lines (every request is a whole line)
+    int preferred = 0;                // ZK_PATH_AUTO picks this kernel over the row-pair kernel
+  };
+  stream_tables stream[2];
 };
+
+// Timing-only ablation builds of the batch kernels (make ABLATE=n -> libzernike_hip_ablate<n>.so; outputs
+// are wrong by construction): 1 = no arithmetic (DMA + LDS reads + stores), 2 = no DMA (arithmetic on
+// stale LDS), 3 = no output stores.  cdna_hip_programming.md section 5.4 rule 17: stubbed values are kept live.
+#ifndef ZK_ABLATE
+#define ZK_ABLATE 0
+#endif
+// Cache policy of the streamed operands: aux = 2 is "nt" (non-temporal).  Every patch byte is read
+// exactly once by one CU and every moment is written once, so both streams bypass cache retention:
+// interleaved A/B on one device, median of 31 rounds (profiles/r01_ablation.txt):
+//   default policy 3.365 ms | nt loads 3.136 | nt loads + nt stores 3.124 | nt stores only 3.288
+#ifndef ZK_DMA_AUX
+#define ZK_DMA_AUX 2
+#endif
+#ifndef ZK_STORE_NT
+#define ZK_STORE_NT 1
+#endif
 
 #ifdef __HIPCC__
 // Row sums of one row pair: S(a, parity of b) of zk_sep.h's header comment.
@@ -215,6 +258,27 @@ struct zk_sep_acc : zk_sep_rows<NMAX> {
   }
   __device__ __forceinline__ void row_end(const ZK_CONST double* py) { row_end_from(*this, py); }
 
+  // Unfolded form (stream batch kernel): X[a] = sum_c f[r][c] P_a(x_c) over (part of) ONE row r;
+  // M_(a,b) += P_b(y_r) X[a] for every slot.  Linear in X, so a row may be flushed in pieces.
+  __device__ __forceinline__ void clear_moments() {
+#pragma unroll
+    for (int i = 0; i < S::NP; ++i) M[i] = 0.0;
+  }
+  template <int s>
+  __device__ __forceinline__ void stream_slot(const double (&X)[S::NA], const ZK_CONST double* py) {
+    M[s] = __builtin_fma(py[S::slot_b(s)], X[S::slot_a(s)], M[s]);
+  }
+  template <int... Is>
+  __device__ __forceinline__ void stream_all(const double (&X)[S::NA], const ZK_CONST double* py,
+                                             std::integer_sequence<int, Is...>) {
+    (stream_slot<Is>(X, py), ...);
+  }
+  __device__ __forceinline__ void stream_row_end(double (&X)[S::NA], const ZK_CONST double* py) {
+    stream_all(X, py, std::make_integer_sequence<int, S::NP>{});
+#pragma unroll
+    for (int a = 0; a < S::NA; ++a) X[a] = 0.0;
+  }
+
   // Z (class-ordered Zernike slots) = T * M, one parity class at a time.  `emit(slot, value)` receives
   // each finished moment; `slot` is a std::integral_constant, so callers can use it both as an int
   // and (decltype(slot)::value) as a compile-time constant.  The T table is [cls][j][i], row-major.
@@ -260,6 +324,49 @@ struct zk_sep_acc : zk_sep_rows<NMAX> {
     transform_class<ZK_OO>(tmat, emit);
   }
 };
+
+// Epilogue of the batch kernels: the wave's 64 x N_poly moments (lane = patch, z in class-ordered
+// slots) become rows of the (N, n_poly) output through a 16-KiB LDS slab and leave as contiguous
+// 16-B-per-lane non-temporal stores.  ppp = patches per pass (host: largest power of two with
+// ppp * n_poly <= 2048); nv = live patches of this wave.
+template <int NP>
+__device__ __forceinline__ void zk_batch_store_rows(const double (&z)[NP], const ZK_CONST int32_t* cmap,
+                                                    double* slab, double* obase, int lane, int nv, int n_poly,
+                                                    int ppp) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  for (int h = 0; h * ppp < 64; ++h) {
+    if (lane / ppp == h) {
+      double* const row = slab + (lane % ppp) * n_poly;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int col = cmap[i];
+        if (col >= 0) row[col] = z[i];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int live = nv - h * ppp;
+    live = live < 0 ? 0 : (live > ppp ? ppp : live);
+    const int vd = live * n_poly;  // doubles to write in this pass
+    double* const dst = obase + (long long)h * ppp * n_poly;
+    for (int k = lane; 2 * k < vd; k += 64) {
+      const f64x2 v = *(const f64x2*)(slab + 2 * k);
+#if ZK_ABLATE == 3
+      asm volatile("" ::"v"(v));
+#else
+      if (2 * k + 2 <= vd) {
+#if ZK_STORE_NT
+        __builtin_nontemporal_store(v, (f64x2*)(dst + 2 * k));
+#else
+        *(f64x2*)(dst + 2 * k) = v;
+#endif
+      } else {
+        dst[2 * k] = v.x;
+      }
+#endif
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next pass overwrites
+  }
+}
 
 // One row pair of the dense kernels: quadrant columns cmin..Q-1 of the LDS-resident window rows `top`
 // (row r) and `bot` (row K-1-r).  Two pixels per iteration through four running pointers, so the loop

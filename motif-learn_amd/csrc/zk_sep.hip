@@ -72,6 +72,11 @@ void zk_sep_free(zk_plan* p) {
     if (b.d_row_starts) (void)hipFree(b.d_row_starts);
   }
   if (t->d_trig) (void)hipFree(t->d_trig);
+  if (t->d_pfull) (void)hipFree(t->d_pfull);
+  for (auto& b : t->stream) {
+    if (b.d_units) (void)hipFree(b.d_units);
+    if (b.d_rows) (void)hipFree(b.d_rows);
+  }
   delete t;
   p->sep = nullptr;
 }
@@ -272,6 +277,51 @@ int zk_sep_build(zk_plan* p, const double* basis) {
     bt.n_row_starts = (int)starts.size();
     if ((rc = upload(&bt.d_units, units))) return rc;
     if ((rc = upload(&bt.d_row_starts, starts))) return rc;
+  }
+
+  // ---- stream batch kernel (zk_sep_stream.hip): full-width table, disk rows and 128-B lines -------
+  {
+    std::vector<double> pfull((size_t)(K + 1) * ZK_SEP_ROW, 0.0);
+    for (int c = 0; c < K; ++c)
+      for (int a = 0; a < D; ++a) pfull[(size_t)c * ZK_SEP_ROW + a] = (double)P[(size_t)c * D + a];
+    if ((rc = upload(&t->d_pfull, pfull))) return rc;
+    std::vector<zk_stream_row> srows;
+    for (int r = 0; r < K; ++r) {
+      int lo = -1, hi = -1;
+      for (int c = 0; c < K; ++c)
+        if (disk[(size_t)r * K + c]) {
+          if (lo < 0) lo = c;
+          hi = c;
+        }
+      if (lo >= 0) srows.push_back({r * K + lo, r * K + hi, r, 0});  // contiguity was checked above
+    }
+    const int n_srows = (int)srows.size();
+    srows.push_back({0x7fffffff, 0x7fffffff, 0, 0});  // sentinel: never reached by a pixel index
+    srows.push_back({0x7fffffff, 0x7fffffff, 0, 0});  // (two: the kernel prefetches one entry ahead)
+    for (int dt = 0; dt < 2; ++dt) {
+      const int es = dt == 0 ? 4 : 8, LW = 128 / es;
+      const long long patch_bytes = (long long)K * K * es;
+      if (K < 8 || K > 1024) continue;
+      // granules that would cross the end of a patch are clamped back into it (their content is then
+      // misplaced), so every disk pixel must lie in the granules below that point
+      if ((long long)(srows[n_srows - 1].te + 1) * es > patch_bytes / 16 * 16) continue;
+      zk_sep_tables::stream_tables& st = t->stream[dt];
+      std::vector<zk_stream_unit> units;
+      int ri = 0;
+      for (long long off = 0; off < patch_bytes; off += 128) {
+        const int t0 = (int)(off / es);
+        while (ri < n_srows && srows[ri].te < t0) ++ri;
+        if (ri == n_srows) break;
+        if (srows[ri].ts >= t0 + LW) continue;  // no disk pixel in this line
+        units.push_back({(int32_t)off, t0, ri, off + 128 > patch_bytes ? 1 : 0});
+      }
+      st.n_units = (int)units.size();
+      st.n_rows = n_srows;
+      st.aligned = patch_bytes % 128 == 0;
+      st.preferred = t->batch[dt].run != 8;  // the row-pair kernel has no whole-line units for this size
+      if ((rc = upload(&st.d_units, units))) return rc;
+      if ((rc = upload(&st.d_rows, srows))) return rc;
+    }
   }
   return 0;
 }

@@ -37,22 +37,6 @@
 // Roofline: algorithmic bytes K*K*s + 8*N_poly per patch (4 456 B at float32 (32, 8)); HBM-bound.
 #include "zk_sep.h"
 
-// Timing-only ablation builds (make ABLATE=n -> libzernike_hip_ablate<n>.so; outputs are wrong by
-// construction): 1 = no arithmetic (DMA + LDS reads + stores), 2 = no DMA (arithmetic on stale LDS),
-// 3 = no output stores.  cdna_hip_programming.md section 5.4 rule 17: stubbed values are kept live.
-#ifndef ZK_ABLATE
-#define ZK_ABLATE 0
-#endif
-// Cache policy of the streamed operands: aux = 2 is "nt" (non-temporal).  Every patch byte is read
-// exactly once by one CU and every moment is written once, so both streams bypass cache retention:
-// interleaved A/B on one device, median of 31 rounds (profiles/r01_ablation.txt):
-//   default policy 3.365 ms | nt loads 3.136 | nt loads + nt stores 3.124 | nt stores only 3.288
-#ifndef ZK_DMA_AUX
-#define ZK_DMA_AUX 2
-#endif
-#ifndef ZK_STORE_NT
-#define ZK_STORE_NT 1
-#endif
 // Unit-order rotation.  Waves start together and walk the same unit list, so at any instant nearly all
 // 2048 resident waves would be fetching the SAME row pair of their patches: addresses that agree in bits
 // 7..11, i.e. a fraction of the HBM channels at a time (the kernel time then moves by ~9 % with the
@@ -64,8 +48,6 @@
 #endif
 
 namespace {
-
-typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 #define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -248,41 +230,8 @@ __global__ __launch_bounds__(256, (NMAX <= 10 ? 2 : 1)) void zk_patch_sep_kernel
   double z[S::NP];
   acc.transform(zk_const(tmat), [&](auto slot, double v) { z[slot] = v; });
   const ZK_CONST int32_t* cmap = zk_const(colmap);
-  double* const slab = (double*)wl;  // 2048 doubles; ppp = patches per pass (host: largest power of
-                                     // two with ppp * n_poly <= 2048)
-  double* const obase = out + patch0 * n_poly;
-  for (int h = 0; h * ppp < 64; ++h) {
-    if (lane / ppp == h) {
-      double* const row = slab + (lane % ppp) * n_poly;
-#pragma unroll
-      for (int i = 0; i < S::NP; ++i) {
-        const int col = cmap[i];
-        if (col >= 0) row[col] = z[i];
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    int live = nv - h * ppp;
-    live = live < 0 ? 0 : (live > ppp ? ppp : live);
-    const int vd = live * n_poly;  // doubles to write in this pass
-    double* const dst = obase + (long long)h * ppp * n_poly;
-    for (int k = lane; 2 * k < vd; k += 64) {
-      const f64x2 v = *(const f64x2*)(slab + 2 * k);
-#if ZK_ABLATE == 3
-      asm volatile("" ::"v"(v));
-#else
-      if (2 * k + 2 <= vd) {
-#if ZK_STORE_NT
-        __builtin_nontemporal_store(v, (f64x2*)(dst + 2 * k));
-#else
-        *(f64x2*)(dst + 2 * k) = v;
-#endif
-      } else {
-        dst[2 * k] = v.x;
-      }
-#endif
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next pass overwrites
-  }
+  // ppp = patches per pass (host: largest power of two with ppp * n_poly <= 2048)
+  zk_batch_store_rows<S::NP>(z, cmap, (double*)wl, out + patch0 * n_poly, lane, nv, n_poly, ppp);
 }
 
 template <int NMAX, int RUN, typename TIN, bool WIDE>

@@ -13,8 +13,8 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, 
 import numpy as np
 
 ZK_F32, ZK_F64 = 0, 1
-PATH_AUTO, PATH_GENERIC, PATH_FOLDED, PATH_SEPARABLE = 0, 1, 2, 3
-PATH_NAMES = {PATH_GENERIC: "generic", PATH_FOLDED: "folded", PATH_SEPARABLE: "separable"}
+PATH_AUTO, PATH_GENERIC, PATH_FOLDED, PATH_SEPARABLE, PATH_STREAM = 0, 1, 2, 3, 4
+PATH_NAMES = {PATH_GENERIC: "generic", PATH_FOLDED: "folded", PATH_SEPARABLE: "separable", PATH_STREAM: "stream"}
 
 # MTFLEARN_AMD_LIB: alternative build of the same ABI (e.g. a timing-only ablation variant)
 LIB_PATH = os.environ.get("MTFLEARN_AMD_LIB") or os.path.join(
@@ -152,7 +152,7 @@ class Plan:
         return bool(self._lib.zk_plan_has_path(self._h, mode, dtype_code_, path))
 
     def best_path(self, mode, dtype_code_):
-        for path in (PATH_SEPARABLE, PATH_FOLDED, PATH_GENERIC):
+        for path in (PATH_SEPARABLE, PATH_STREAM, PATH_FOLDED, PATH_GENERIC):
             if self.has_path(mode, dtype_code_, path):
                 return path
 

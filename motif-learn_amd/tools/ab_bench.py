@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=15)
     ap.add_argument("--mode", choices=["patches", "frame"], default="patches")
     ap.add_argument("--f64", action="store_true", help="float64 operands")
-    ap.add_argument("--path", type=int, default=0, help="ZK_PATH_* to force (0 auto, 1 generic, 2 folded, 3 separable)")
+    ap.add_argument("--path", type=int, default=0, help="ZK_PATH_* to force (0 auto, 1 generic, 2 folded, 3 separable, 4 stream)")
     args = ap.parse_args()
 
     torch.cuda.set_device(0)
