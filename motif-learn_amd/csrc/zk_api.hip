@@ -180,11 +180,12 @@ static bool path_available(const zk_plan* p, int mode, int dtype, int path) {
   return false;
 }
 
-// ZK_PATH_AUTO: separable (batches: its stream form where the plan prefers it), else folded (frame), else generic
-static int resolve_path(const zk_plan* p, int mode, int dtype) {
+// ZK_PATH_AUTO: separable (batches: its stream form where the plan prefers it), else folded (frame), else generic.
+// `n_units` = patches of the call (batch mode).
+static int resolve_path(const zk_plan* p, int mode, int dtype, int64_t n_units = 0) {
   if (p->path != ZK_PATH_AUTO) return path_available(p, mode, dtype, p->path) ? p->path : -1;
   if (mode == 0 && path_available(p, mode, dtype, ZK_PATH_STREAM) &&
-      (zk_sep_stream_preferred(p, dtype) || !path_available(p, mode, dtype, ZK_PATH_SEPARABLE)))
+      (zk_sep_stream_preferred(p, dtype, n_units) || !path_available(p, mode, dtype, ZK_PATH_SEPARABLE)))
     return ZK_PATH_STREAM;
   if (path_available(p, mode, dtype, ZK_PATH_SEPARABLE)) return ZK_PATH_SEPARABLE;
   if (path_available(p, mode, dtype, ZK_PATH_FOLDED)) return ZK_PATH_FOLDED;
@@ -224,7 +225,7 @@ extern "C" int zk_transform_patches_dev(zk_plan* p, const void* patches, int dty
   if (!patches || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
   ZK_HIP(hipSetDevice(p->device));
   hipStream_t s = (hipStream_t)hip_stream;  // exactly the caller's stream; NULL is HIP's default stream
-  const int path = resolve_path(p, 0, dtype);
+  const int path = resolve_path(p, 0, dtype, n_patches);
   if (path < 0) return zk_fail(ZK_E_BADARG, "the forced kernel path is not available for this plan / dtype");
   if (path == ZK_PATH_SEPARABLE) return zk_launch_sep_patches(p, patches, dtype, n_patches, out, s);
   if (path == ZK_PATH_STREAM) return zk_launch_sep_stream(p, patches, dtype, n_patches, out, s);

@@ -90,7 +90,7 @@ int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patch
                           hipStream_t s);
 // stream form of the batch kernel (zk_sep_stream.hip)
 bool zk_sep_stream_available(const zk_plan* p, int dtype);
-bool zk_sep_stream_preferred(const zk_plan* p, int dtype);
+bool zk_sep_stream_preferred(const zk_plan* p, int dtype, int64_t n_patches);
 int zk_launch_sep_stream(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s);
 int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                        const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,

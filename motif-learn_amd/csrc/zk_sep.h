@@ -95,6 +95,8 @@ struct zk_sep_unit {    // batch kernel: 16 (float32) / 8 (float64) quadrant col
                         // belongs to the second row (K-1-r) of the pair; bits 8..: cmax = ceil(K/2)
 };
 
+#define ZK_STREAM_PAD 4  // zero rows either side of the stream kernel's Legendre table (one granule of pixels)
+
 // Stream ("flat") batch kernel, zk_sep_stream.hip: a patch is read as the contiguous pixel stream it is
 // in memory, one 128-B line per unit, whatever K is.
 struct zk_stream_row {  // one patch row with disk pixels, in flat pixel indices t = r * K + c
@@ -135,7 +137,8 @@ struct zk_sep_tables {
   };
   batch_tables batch[2];
   // stream batch kernel: full-width Legendre table + row / line lists per element type
-  double* d_pfull = nullptr;          // [K + 1][ZK_SEP_ROW] P_a(x_c) for all K columns; row K is zero
+  double* d_pfull_alloc = nullptr;    // ZK_STREAM_PAD zero rows | [K][ZK_SEP_ROW] | ZK_STREAM_PAD zero rows
+  double* d_pfull = nullptr;          // row 0 of it: P_1(x_c) .. P_nmax(x_c) for column c (P_0 = 1 is implicit)
   struct stream_tables {
     int n_units = 0;
     zk_stream_unit* d_units = nullptr;
@@ -264,9 +267,12 @@ struct zk_sep_acc : zk_sep_rows<NMAX> {
 #pragma unroll
     for (int i = 0; i < S::NP; ++i) M[i] = 0.0;
   }
+  // py = P_1(y_r) .. P_nmax(y_r) (the stream kernel's table has no P_0 column: P_0 = 1)
   template <int s>
   __device__ __forceinline__ void stream_slot(const double (&X)[S::NA], const ZK_CONST double* py) {
-    M[s] = __builtin_fma(py[S::slot_b(s)], X[S::slot_a(s)], M[s]);
+    constexpr int b = S::slot_b(s);
+    if constexpr (b == 0) M[s] += X[S::slot_a(s)];
+    else M[s] = __builtin_fma(py[b - 1], X[S::slot_a(s)], M[s]);
   }
   template <int... Is>
   __device__ __forceinline__ void stream_all(const double (&X)[S::NA], const ZK_CONST double* py,

@@ -72,7 +72,7 @@ void zk_sep_free(zk_plan* p) {
     if (b.d_row_starts) (void)hipFree(b.d_row_starts);
   }
   if (t->d_trig) (void)hipFree(t->d_trig);
-  if (t->d_pfull) (void)hipFree(t->d_pfull);
+  if (t->d_pfull_alloc) (void)hipFree(t->d_pfull_alloc);
   for (auto& b : t->stream) {
     if (b.d_units) (void)hipFree(b.d_units);
     if (b.d_rows) (void)hipFree(b.d_rows);
@@ -281,10 +281,11 @@ int zk_sep_build(zk_plan* p, const double* basis) {
 
   // ---- stream batch kernel (zk_sep_stream.hip): full-width table, disk rows and 128-B lines -------
   {
-    std::vector<double> pfull((size_t)(K + 1) * ZK_SEP_ROW, 0.0);
+    std::vector<double> pfull((size_t)(K + 2 * ZK_STREAM_PAD) * ZK_SEP_ROW, 0.0);
     for (int c = 0; c < K; ++c)
-      for (int a = 0; a < D; ++a) pfull[(size_t)c * ZK_SEP_ROW + a] = (double)P[(size_t)c * D + a];
-    if ((rc = upload(&t->d_pfull, pfull))) return rc;
+      for (int a = 1; a < D; ++a) pfull[(size_t)(c + ZK_STREAM_PAD) * ZK_SEP_ROW + a - 1] = (double)P[(size_t)c * D + a];
+    if ((rc = upload(&t->d_pfull_alloc, pfull))) return rc;
+    t->d_pfull = t->d_pfull_alloc + ZK_STREAM_PAD * ZK_SEP_ROW;
     std::vector<zk_stream_row> srows;
     for (int r = 0; r < K; ++r) {
       int lo = -1, hi = -1;
@@ -318,7 +319,9 @@ int zk_sep_build(zk_plan* p, const double* basis) {
       st.n_units = (int)units.size();
       st.n_rows = n_srows;
       st.aligned = patch_bytes % 128 == 0;
-      st.preferred = t->batch[dt].run != 8;  // the row-pair kernel has no whole-line units for this size
+      // preferred where the row-pair kernel has no whole-line units, except the sizes at which its 64-B runs
+      // pair up inside lines anyway and it measures level or ahead (tools/sweep_batch.py)
+      st.preferred = t->batch[dt].run != 8 && K != 16 && !(dt == 0 && K % 32 == 0);
       if ((rc = upload(&st.d_units, units))) return rc;
       if ((rc = upload(&st.d_rows, srows))) return rc;
     }

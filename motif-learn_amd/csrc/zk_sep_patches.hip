@@ -1,6 +1,7 @@
 // zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157): HBM-streaming,
 // LDS-DMA transposed, row-separable arithmetic.  float32 patches of any size K >= 16 and float64 patches
 // of any size K >= 8, odd sizes included (LDS-DMA sources only need element alignment); n_max <= 12.
+// (Large batches of sizes that get no whole-line units here go to zk_sep_stream.hip under ZK_PATH_AUTO.)
 //
 // Work decomposition.  One wave owns 64 consecutive patches, one patch per lane, and keeps that
 // patch's accumulators in VGPRs for the whole patch, so every multiplier that is not a pixel is

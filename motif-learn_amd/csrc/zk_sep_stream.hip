@@ -15,9 +15,10 @@
 //             from LDS (a granule ahead), unit k+2 is issued into the slab unit k leaves.
 //
 // Arithmetic: the row-separable sum of zk_sep.h WITHOUT mirror folding (the mirror pixels of a stream
-// position live in other lines): per disk pixel (n_max+1) v_fma_f64 into the row sums X_a, per disk row
-// N_poly v_fma_f64 (M_(a,b) += P_b(y_r) X_a), one class-blocked T product per patch.  ~1.4x the f64 work
-// of the folded kernel at (32, 8); still hidden behind the stream up to n_max 10.  The position in the
+// position live in other lines): per disk pixel n_max v_fma_f64 + one v_add_f64 (P_0 = 1) into the row sums
+// X_a, per disk row N_poly v_fma_f64 (M_(a,b) += P_b(y_r) X_a), one class-blocked T product per patch.
+// ~1.4x the f64 work of the folded kernel at (32, 8): hidden behind the stream for float64 patches and for
+// float32 up to n_max 8, issue-bound above (profiles/r01_stream_sweep.txt).  The position in the
 // stream -- row, column, inside the disk or not -- is wave-uniform and lives in SGPRs; a row may be flushed
 // in pieces (the sums are linear), so a wave can start at any line of the patch (channel spreading, see
 // ZK_ROTATE in zk_sep_patches.hip).
@@ -36,7 +37,7 @@ namespace {
 #define ZK_STREAM_WPB (ZK_STREAM_WG / 64)
 
 template <int NMAX, typename TIN>
-__global__ __launch_bounds__(ZK_STREAM_WG, (NMAX <= 10 ? 2 : 1)) void zk_patch_stream_kernel(
+__global__ __launch_bounds__(ZK_STREAM_WG, 2) void zk_patch_stream_kernel(
     const TIN* __restrict__ in, double* __restrict__ out, const zk_stream_unit* __restrict__ units,
     const zk_stream_row* __restrict__ rows, const double* __restrict__ pfull, const double* __restrict__ tmat,
     const int32_t* __restrict__ colmap, int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp,
@@ -151,33 +152,28 @@ __global__ __launch_bounds__(ZK_STREAM_WG, (NMAX <= 10 ? 2 : 1)) void zk_patch_s
         // The loop body is straight-line code plus ONE conditional block, the row end (with any more
         // control flow around the moment updates the compiler keeps two copies of M and moves them every
         // granule), and scalar instructions are kept to a minimum: a wave issues them at the same rate
-        // as its v_fma_f64.  All table rows of a granule are requested before the first FMA (one
-        // scalar-memory wait per granule), so no FMA is conditional on a pixel being inside the disk:
-        // a pixel outside it, or past the end of the current row, takes the zero row of the table.  (A
-        // NaN at such a position therefore reaches the moments -- as it does in the reference, where any
-        // NaN in the patch does; the other kernels never read pixels outside the disk.)
-        const ZK_CONST double* xp[PXG];
-        if (tg >= ts && tg + PXG - 1 <= te) {  // interior of the current row: consecutive table rows
-          const ZK_CONST double* base = xcur + tg * ZK_SEP_ROW;
+        // as its v_fma_f64.  The table rows of the granule's four columns are requested together (one
+        // scalar-memory wait per granule) from xcur + tg * ROW onwards, whether or not the pixels are
+        // inside the disk -- the table has ZK_STREAM_PAD spare rows either side -- and the pixels that
+        // are not (or that lie behind the end of the current row) are zeroed instead, which only happens
+        // in the granules where a row begins or ends.
+        gran_t vm = v;
+        if (tg < ts || tg + PXG - 1 > te) {
 #pragma unroll
-          for (int e = 0; e < PXG; ++e) xp[e] = base + e * ZK_SEP_ROW;
-        } else {
-#pragma unroll
-          for (int e = 0; e < PXG; ++e) {
-            const int t = tg + e;
-            xp[e] = (t >= ts && t <= te) ? xcur + t * ZK_SEP_ROW : zrow;
-          }
+          for (int e = 0; e < PXG; ++e) vm[e] = (tg + e >= ts && tg + e <= te) ? v[e] : (TIN)0;
         }
-        double xv[PXG][S::NA];
+        const ZK_CONST double* base = xcur + tg * ZK_SEP_ROW;
+        double xv[PXG][S::NA - 1];
 #pragma unroll
         for (int e = 0; e < PXG; ++e)
 #pragma unroll
-          for (int i = 0; i < S::NA; ++i) xv[e][i] = xp[e][i];
+          for (int i = 0; i < S::NA - 1; ++i) xv[e][i] = base[e * ZK_SEP_ROW + i];
 #pragma unroll
         for (int e = 0; e < PXG; ++e) {
-          const double f = (double)v[e];
+          const double f = (double)vm[e];
+          X[0] += f;  // P_0 = 1
 #pragma unroll
-          for (int i = 0; i < S::NA; ++i) X[i] = __builtin_fma(f, xv[e][i], X[i]);
+          for (int i = 1; i < S::NA; ++i) X[i] = __builtin_fma(f, xv[e][i - 1], X[i]);
         }
         if (te < tg + PXG) {  // the current row ends in this granule; pixels behind its end may already
                               // belong to the next row (a granule touches at most two rows: a row is longer)
@@ -186,10 +182,12 @@ __global__ __launch_bounds__(ZK_STREAM_WG, (NMAX <= 10 ? 2 : 1)) void zk_patch_s
 #pragma unroll
           for (int e = 1; e < PXG; ++e) {
             const int t = tg + e;
-            const ZK_CONST double* xn = (t >= ts && t <= te) ? xcur + t * ZK_SEP_ROW : zrow;
-            const double f = (double)v[e];
+            const bool in = t >= ts && t <= te;
+            const ZK_CONST double* xn = in ? xcur + t * ZK_SEP_ROW : zrow;
+            const double f = (double)(in ? v[e] : (TIN)0);
+            X[0] += f;
 #pragma unroll
-            for (int i = 0; i < S::NA; ++i) X[i] = __builtin_fma(f, xn[i], X[i]);
+            for (int i = 1; i < S::NA; ++i) X[i] = __builtin_fma(f, xn[i - 1], X[i]);
           }
         }
       }
@@ -246,8 +244,11 @@ bool zk_sep_stream_available(const zk_plan* p, int dtype) {
   return t && t->stream[dtype == ZK_F32 ? 0 : 1].n_units > 0 && p->n_poly <= 1024 && p->size <= 1024;
 }
 
-bool zk_sep_stream_preferred(const zk_plan* p, int dtype) {
-  return p->sep && p->sep->stream[dtype == ZK_F32 ? 0 : 1].preferred;
+// ZK_PATH_AUTO takes this kernel where the row-pair kernel has no whole-line units for the patch size and
+// the batch fills the chip: a wave keeps 8-16 KiB in flight here against 16 KiB there, so with fewer waves
+// than wave slots (2048) the row-pair kernel is ahead (tools/sweep_batch.py, profiles/r01_stream_sweep.txt).
+bool zk_sep_stream_preferred(const zk_plan* p, int dtype, int64_t n_patches) {
+  return p->sep && p->sep->stream[dtype == ZK_F32 ? 0 : 1].preferred && n_patches >= 98304;
 }
 
 int zk_launch_sep_stream(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {

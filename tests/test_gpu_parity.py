@@ -258,6 +258,59 @@ def test_frame_shapes_vs_oracle(native, zo, n_max, size, shape, dtype):
         rel_close(got, ref, atol_scale=1e-11 if (name == "separable" and n_max > 10) else 1e-12)
 
 
+@pytest.mark.parametrize("n_max,size,dtype", [(6, 24, np.float32), (8, 33, np.float32), (10, 12, np.float64)])
+def test_large_batch_auto_path_is_stream(native, zo, n_max, size, dtype):
+    """Batches that fill the chip (>= 98304 patches) of a size without whole-line row units: ZK_PATH_AUTO
+    runs the stream kernel; it must agree with the row-pair / generic kernels and with the oracle, tail
+    wave included."""
+    z = _zps(n_max, size)
+    plan = z._device_plan()
+    code = native.dtype_code(np.dtype(dtype))
+    assert plan.has_path(0, code, native.PATH_STREAM)
+    rng = np.random.default_rng(11)
+    n = 98304 + 1237
+    patches = rng.random((n, size, size)).astype(dtype)
+    auto = plan.transform_patches(patches)
+    plan.set_path(native.PATH_STREAM)
+    forced = plan.transform_patches(patches)
+    plan.set_path(native.PATH_GENERIC)
+    generic = plan.transform_patches(patches)
+    plan.set_path(native.PATH_AUTO)
+    np.testing.assert_array_equal(auto, forced)          # AUTO took the stream kernel: bit-identical
+    rel_close(auto, generic)
+    pick = np.r_[0:150, n - 150:n]
+    rel_close(auto[pick], zo.moments_patches(patches[pick], z.polynomials))
+
+
+@pytest.mark.parametrize("n_max,size,dtype", [(8, 32, np.float32), (8, 24, np.float32), (6, 33, np.float32),
+                                              (8, 64, np.float32), (6, 16, np.float64)])
+def test_non_finite_pixels(native, n_max, size, dtype):
+    """A NaN outside the unit disk is never used by the fast kernels; a NaN inside
+    it reaches every moment of its patch, as in the reference."""
+    z = _zps(n_max, size)
+    disk = np.any(z.polynomials != 0, axis=0)
+    rng = np.random.default_rng(12)
+    clean = rng.random((130, size, size)).astype(dtype)
+    dirty = clean.copy()
+    dirty[:, ~disk] = np.nan
+    inside = clean.copy()
+    rows, cols = np.nonzero(disk)
+    for p in range(inside.shape[0]):
+        k = rng.integers(len(rows))
+        inside[p, rows[k], cols[k]] = np.nan
+    for name, path in [("separable", native.PATH_SEPARABLE), ("stream", native.PATH_STREAM)]:
+        plan = z._device_plan()
+        if not plan.has_path(0, native.dtype_code(np.dtype(dtype)), path):
+            continue
+        plan.set_path(path)
+        try:
+            ref = plan.transform_patches(clean)
+            np.testing.assert_array_equal(plan.transform_patches(dirty), ref, err_msg=name)
+            assert np.isnan(plan.transform_patches(inside)).all(), name
+        finally:
+            plan.set_path(native.PATH_AUTO)
+
+
 def test_zero_and_constant_inputs(native):
     z = _zps(8, 32)
     assert not z.transform(np.zeros((5, 32, 32), np.float32)).data.any()
