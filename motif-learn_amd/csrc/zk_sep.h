@@ -23,7 +23,7 @@
 // and a finished row pair r adds  M_(a,b) += P_b(y_r) * S(a, parity of b).
 //
 // Numerics: T is built in extended precision on the host (zk_sep.hip); its entries reach ~2e2 at
-// n_max = 8 (~1e3 at 10), so the result carries ~1e-13 * max|Z| of rounding where the direct sum
+// n_max = 8 (~1e3 at 10, ~2e5 at 16), so the result carries ~1e-13 (1e-11 at 16) * max|Z| of rounding where the direct sum
 // carries ~1e-15 -- seven orders inside the 1e-6 parity tolerance.  The plan verifies at creation
 // that T reproduces the caller's basis at every disk pixel and otherwise disables this path.
 #pragma once
@@ -79,7 +79,9 @@ struct zk_sep_set {
   }
 };
 
-#define ZK_SEP_ROW 16  // doubles per row of the P-value tables (degrees 0..15, 128-B aligned rows)
+#ifndef ZK_SEP_ROW
+#define ZK_SEP_ROW 24  // doubles per row of the P-value tables (degrees 0..16 used; rows start on 64-B lines)
+#endif
 
 struct zk_sep_row {     // one quadrant row pair (r, K-1-r) with at least one disk pixel
   int32_t r;            // row index
@@ -270,9 +272,9 @@ struct zk_sep_acc : zk_sep_rows<NMAX> {
   // py = P_1(y_r) .. P_nmax(y_r) (the stream kernel's table has no P_0 column: P_0 = 1)
   template <int s>
   __device__ __forceinline__ void stream_slot(const double (&X)[S::NA], const ZK_CONST double* py) {
-    constexpr int b = S::slot_b(s);
-    if constexpr (b == 0) M[s] += X[S::slot_a(s)];
-    else M[s] = __builtin_fma(py[b - 1], X[S::slot_a(s)], M[s]);
+    constexpr int a = S::slot_a(s), b = S::slot_b(s);  // (constexpr: otherwise evaluated at run time for large NMAX)
+    if constexpr (b == 0) M[s] += X[a];
+    else M[s] = __builtin_fma(py[b - 1], X[a], M[s]);
   }
   template <int... Is>
   __device__ __forceinline__ void stream_all(const double (&X)[S::NA], const ZK_CONST double* py,
@@ -340,6 +342,7 @@ __device__ __forceinline__ void zk_batch_store_rows(const double (&z)[NP], const
                                                     double* slab, double* obase, int lane, int nv, int n_poly,
                                                     int ppp) {
   typedef double f64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 1
   for (int h = 0; h * ppp < 64; ++h) {
     if (lane / ppp == h) {
       double* const row = slab + (lane % ppp) * n_poly;

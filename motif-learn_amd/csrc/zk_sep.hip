@@ -8,7 +8,7 @@
 
 typedef long double ld;
 
-static const int kSepNmax[] = {4, 6, 8, 10, 12};  // instantiated kernels (12: dense + points kernels only)
+static const int kSepNmax[] = {4, 6, 8, 10, 12, 14, 16};  // instantiated kernels
 
 // x^a = sum_i L[a][i] P_i(x), from x P_i = ((i+1) P_{i+1} + i P_{i-1}) / (2i+1); all terms positive.
 static std::vector<std::vector<ld>> monomial_to_legendre(int deg) {
@@ -320,8 +320,9 @@ int zk_sep_build(zk_plan* p, const double* basis) {
       st.n_rows = n_srows;
       st.aligned = patch_bytes % 128 == 0;
       // preferred where the row-pair kernel has no whole-line units, except the sizes at which its 64-B runs
-      // pair up inside lines anyway and it measures level or ahead (tools/sweep_batch.py)
-      st.preferred = t->batch[dt].run != 8 && K != 16 && !(dt == 0 && K % 32 == 0);
+      // pair up inside lines anyway and it measures level or ahead, and n_max > 12, where both kernels are
+      // bound by arithmetic and the folded one does less of it (tools/sweep_batch.py)
+      st.preferred = t->batch[dt].run != 8 && K != 16 && !(dt == 0 && K % 32 == 0) && knm <= 12;
       if ((rc = upload(&st.d_units, units))) return rc;
       if ((rc = upload(&st.d_rows, srows))) return rc;
     }

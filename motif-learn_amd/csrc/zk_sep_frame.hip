@@ -90,6 +90,8 @@ int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int
     case 8: return launch_one<8, T>(p, in, H, W, row0, n_rows, out, s);
     case 10: return launch_one<10, T>(p, in, H, W, row0, n_rows, out, s);
     case 12: return launch_one<12, T>(p, in, H, W, row0, n_rows, out, s);
+    case 14: return launch_one<14, T>(p, in, H, W, row0, n_rows, out, s);
+    case 16: return launch_one<16, T>(p, in, H, W, row0, n_rows, out, s);
   }
   return zk_fail(ZK_E_BADARG, "no separable frame kernel for this n_max");
 }

@@ -212,6 +212,8 @@ int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int
     case 8: return launch_one<8, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
     case 10: return launch_one<10, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
     case 12: return launch_one<12, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 14: return launch_one<14, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 16: return launch_one<16, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
   }
   return zk_fail(ZK_E_BADARG, "no fused maps kernel for this n_max");
 }
@@ -222,7 +224,7 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
                        const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
                        const double* theta, int n_theta, double* rot, double* ab, double* mirror, hipStream_t s) {
   if (!zk_sep_frame_available(p, dtype))
-    return zk_fail(ZK_E_BADARG, "plan has no fused maps kernel (needs the separable tables: n_max <= 12)");
+    return zk_fail(ZK_E_BADARG, "plan has no fused maps kernel (needs the separable tables: n_max <= 16)");
   if (n_folds < 0 || n_folds > ZK_MAX_FOLDS) return zk_fail(ZK_E_BADARG, "at most 8 folds per call");
   if (p_norm != 0 && p_norm != 2) return zk_fail(ZK_E_BADARG, "p must be 2 or 0 (None)");
   if (rot && (!folds || n_folds == 0)) return zk_fail(ZK_E_BADARG, "rot output requested without folds");

@@ -1,6 +1,6 @@
 // zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157): HBM-streaming,
 // LDS-DMA transposed, row-separable arithmetic.  float32 patches of any size K >= 16 and float64 patches
-// of any size K >= 8, odd sizes included (LDS-DMA sources only need element alignment); n_max <= 12.
+// of any size K >= 8, odd sizes included (LDS-DMA sources only need element alignment); n_max <= 16.
 // (Large batches of sizes that get no whole-line units here go to zk_sep_stream.hip under ZK_PATH_AUTO.)
 //
 // Work decomposition.  One wave owns 64 consecutive patches, one patch per lane, and keeps that
@@ -261,6 +261,8 @@ int launch_run(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
     case 8: return launch_one<8, RUN, TIN, WIDE>(p, in, n_patches, out, s);
     case 10: return launch_one<10, RUN, TIN, WIDE>(p, in, n_patches, out, s);
     case 12: return launch_one<12, RUN, TIN, WIDE>(p, in, n_patches, out, s);
+    case 14: return launch_one<14, RUN, TIN, WIDE>(p, in, n_patches, out, s);
+    case 16: return launch_one<16, RUN, TIN, WIDE>(p, in, n_patches, out, s);
   }
   return zk_fail(ZK_E_BADARG, "no batch kernel for this n_max");
 }

@@ -72,6 +72,8 @@ int launch_t(zk_plan* p, const void* img, const int32_t* pts, int64_t H, int64_t
     case 8: return launch_one<8, T>(p, img, pts, H, W, n_points, out, s);
     case 10: return launch_one<10, T>(p, img, pts, H, W, n_points, out, s);
     case 12: return launch_one<12, T>(p, img, pts, H, W, n_points, out, s);
+    case 14: return launch_one<14, T>(p, img, pts, H, W, n_points, out, s);
+    case 16: return launch_one<16, T>(p, img, pts, H, W, n_points, out, s);
   }
   return zk_fail(ZK_E_BADARG, "no point kernel for this n_max");
 }

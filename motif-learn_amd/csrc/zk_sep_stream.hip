@@ -1,6 +1,6 @@
 // zk_sep_stream.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157) for patch sizes whose
 // rows are not a whole number of 128-B lines: the patch is read as the contiguous pixel stream it is in
-// memory, one 128-B line at a time, whatever K is (float32 / float64, any K >= 8, n_max <= 12).
+// memory, one 128-B line at a time, whatever K is (float32 / float64, any K >= 8, n_max <= 16).
 //
 // Same work decomposition as zk_sep_patches.hip -- one wave owns 64 consecutive patches, one patch per
 // lane, accumulators in VGPRs, wave-uniform multipliers through scalar loads, LDS-DMA transposition with
@@ -37,7 +37,7 @@ namespace {
 #define ZK_STREAM_WPB (ZK_STREAM_WG / 64)
 
 template <int NMAX, typename TIN>
-__global__ __launch_bounds__(ZK_STREAM_WG, 2) void zk_patch_stream_kernel(
+__global__ __launch_bounds__(ZK_STREAM_WG, (NMAX <= 12 ? 2 : 1)) void zk_patch_stream_kernel(
     const TIN* __restrict__ in, double* __restrict__ out, const zk_stream_unit* __restrict__ units,
     const zk_stream_row* __restrict__ rows, const double* __restrict__ pfull, const double* __restrict__ tmat,
     const int32_t* __restrict__ colmap, int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp,
@@ -232,6 +232,8 @@ int launch_t(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStre
     case 8: return launch_one<8, TIN>(p, in, n_patches, out, s);
     case 10: return launch_one<10, TIN>(p, in, n_patches, out, s);
     case 12: return launch_one<12, TIN>(p, in, n_patches, out, s);
+    case 14: return launch_one<14, TIN>(p, in, n_patches, out, s);
+    case 16: return launch_one<16, TIN>(p, in, n_patches, out, s);
   }
   return zk_fail(ZK_E_BADARG, "no stream batch kernel for this n_max");
 }
