@@ -79,6 +79,49 @@ struct zk_sep_set {
   }
 };
 
+// Sparsity of T: the Zernike function of radial order n has total degree n, so T[j][(a,b)] = 0 for
+// a + b > n_j.  The device table stores, per class, the rows of T packed to their a + b <= n_j entries
+// (in slot order); these compile-time tables give every kernel the same addressing (about half of the
+// class-block entries are structural zeros).
+template <int NMAX>
+struct zk_sep_pack {
+  using S = zk_sep_set<NMAX>;
+  using Z = zk_set<NMAX>;
+  struct tables {
+    int deg[S::NP];        // a + b of each Legendre-product slot
+    int zn[S::NP];         // radial order of each Zernike slot (same class order)
+    int row_begin[S::NP];  // offset of the packed row of Zernike slot j in the device table
+    int total;
+  };
+  static constexpr tables make() {
+    tables t = {};
+    for (int s = 0; s < S::NP; ++s) {
+      t.deg[s] = S::slot_a(s) + S::slot_b(s);
+      t.zn[s] = Z::slot_n(s);
+    }
+    int o = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int b = S::cls_begin(cls), n = S::cls_count(cls);
+      for (int j = 0; j < n; ++j) {
+        t.row_begin[b + j] = o;
+        for (int i = 0; i < n; ++i) o += t.deg[b + i] <= t.zn[b + j];
+      }
+    }
+    t.total = o;
+    return t;
+  }
+};
+template <int NMAX>
+struct zk_sep_meta {
+  static constexpr typename zk_sep_pack<NMAX>::tables tab = zk_sep_pack<NMAX>::make();
+  // position of entry (j, i) inside the packed row of j (valid when deg[i] <= zn[j]); slots are global
+  static constexpr int pos(int cls_begin, int j, int i) {
+    int k = 0;
+    for (int q = cls_begin; q < i; ++q) k += tab.deg[q] <= tab.zn[j];
+    return k;
+  }
+};
+
 #ifndef ZK_SEP_ROW
 #define ZK_SEP_ROW 24  // doubles per row of the P-value tables (degrees 0..16 used; rows start on 64-B lines)
 #endif
@@ -120,7 +163,7 @@ struct zk_sep_tables {
   int Q = 0;                       // quadrant side ceil(K/2)
   double* d_xq = nullptr;          // [Q][ZK_SEP_ROW] P_a(x_c) (x 0.5 on the centre column of odd K)
   double* d_yq = nullptr;          // [Q][ZK_SEP_ROW] P_b(y_r) (x 0.5 on the centre row)
-  double* d_T = nullptr;           // class blocks, [cls][j][i] row-major, scaled by 1/area
+  double* d_T = nullptr;           // class blocks [cls][j], each row packed to its a + b <= n_j entries (zk_sep_pack), scaled by 1/area
   int32_t* d_colmap = nullptr;     // [np_kernel] class-ordered Zernike slot -> output column or -1
   int n_rows = 0;
   zk_sep_row* d_rows = nullptr;    // [n_rows]
@@ -289,20 +332,28 @@ struct zk_sep_acc : zk_sep_rows<NMAX> {
 
   // Z (class-ordered Zernike slots) = T * M, one parity class at a time.  `emit(slot, value)` receives
   // each finished moment; `slot` is a std::integral_constant, so callers can use it both as an int
-  // and (decltype(slot)::value) as a compile-time constant.  The T table is [cls][j][i], row-major.
-  template <int CLS>
-  static constexpr int t_offset() {
-    int o = 0;
-    for (int c = 0; c < CLS; ++c) o += S::cls_count(c) * S::cls_count(c);
-    return o;
+  // and (decltype(slot)::value) as a compile-time constant.  The T table holds the packed rows of
+  // zk_sep_pack (entries with a + b <= n_j only).
+  template <int JS, int I>
+  __device__ __forceinline__ void transform_term(const ZK_CONST double* tb, double& z) {
+    using P = zk_sep_meta<NMAX>;
+    constexpr int cb = S::cls_begin(S::cls_of(S::slot_a(JS), S::slot_b(JS)));
+    if constexpr (P::tab.deg[cb + I] <= P::tab.zn[JS]) {
+      constexpr int k = P::pos(cb, JS, cb + I);
+      z = __builtin_fma(tb[k], M[cb + I], z);
+    }
+  }
+  template <int JS, int... Is>
+  __device__ __forceinline__ void transform_terms(const ZK_CONST double* tb, double& z, std::integer_sequence<int, Is...>) {
+    (transform_term<JS, Is>(tb, z), ...);
   }
   template <int CLS, int J, typename F>
   __device__ __forceinline__ void transform_row(const ZK_CONST double* tmat, F&& emit) {
     constexpr int n = S::cls_count(CLS), off = S::cls_begin(CLS);
-    const ZK_CONST double* tb = tmat + t_offset<CLS>() + J * n;
+    constexpr int rb = zk_sep_meta<NMAX>::tab.row_begin[off + J];
+    const ZK_CONST double* tb = tmat + rb;
     double z = 0.0;
-#pragma unroll
-    for (int i = 0; i < n; ++i) z = __builtin_fma(tb[i], M[off + i], z);
+    transform_terms<off + J>(tb, z, std::make_integer_sequence<int, n>{});
     emit(std::integral_constant<int, off + J>{}, z);
     // keep the scheduler from hoisting every row's scalar loads to the top (hundreds of SGPRs)
     __builtin_amdgcn_sched_barrier(0);

@@ -179,10 +179,14 @@ int zk_sep_build(zk_plan* p, const double* basis) {
   const ld inv_area = 1.0L / (M_PIl * (ld)K * (ld)K / 4.0L);
   for (int cls = 0; cls < 4; ++cls) {
     std::vector<int> zj;  // plan column of each Zernike slot of this class (or -1)
+    std::vector<int> zn;  // its radial order
     int j = 0;
     for (int n = 0; n <= knm; ++n)
       for (int m = -n; m <= n; m += 2, ++j)
-        if (zk_class_of(m) == cls) zj.push_back(n <= n_max ? j : -1);
+        if (zk_class_of(m) == cls) {
+          zj.push_back(n <= n_max ? j : -1);
+          zn.push_back(n);
+        }
     std::vector<std::pair<int, int>> ab;
     for (int a = 0; a <= knm; ++a)
       for (int b = 0; a + b <= knm; ++b) {
@@ -193,8 +197,13 @@ int zk_sep_build(zk_plan* p, const double* basis) {
     for (size_t jj = 0; jj < zj.size(); ++jj) {
       colmap.push_back(zj[jj]);
       for (size_t ii = 0; ii < ab.size(); ++ii) {
+        const bool structural_zero = ab[ii].first + ab[ii].second > zn[jj];  // total degree of V_j is n_j
         ld v = 0.0L;
         if (zj[jj] >= 0) v = Tfull[((size_t)zj[jj] * D + ab[ii].first) * D + ab[ii].second] * inv_area;
+        if (structural_zero) {
+          if (v != 0.0L) return zk_fail(ZK_E_BADARG, "internal: T entry above the polynomial degree");
+          continue;  // packed rows: the kernels skip these entries (zk_sep_pack)
+        }
         Tdev.push_back((double)v);
       }
     }
