@@ -46,7 +46,8 @@ extern "C" {
 #define ZK_PATH_AUTO      0
 #define ZK_PATH_GENERIC   1  /* any size / n_max / dtype: unfolded direct summation, ~1e-16 of the definition */
 #define ZK_PATH_FOLDED    2  /* frame only: mirror-folded direct summation (4x fewer FMAs), ~1e-15            */
-#define ZK_PATH_SEPARABLE 3  /* mirror-folded row-separable sums (Legendre products), ~1e-13; fastest       */
+#define ZK_PATH_SEPARABLE 3  /* mirror-folded row-separable sums (Legendre products), ~1e-13; fastest.  Full
+                                Zernike sets up to n_max 20 (17-20: one pass per mirror-parity class, ~1e-9) */
 #define ZK_PATH_STREAM    4  /* patches only: row-separable sums over the contiguous pixel stream of a patch,
                                 whole 128-B lines whatever the patch size; AUTO prefers it where the row-pair
                                 kernel of ZK_PATH_SEPARABLE would issue half-line requests */
@@ -74,6 +75,12 @@ void zk_plan_destroy(zk_plan* plan);
 
 /* Introspection: 1 if `path` (ZK_PATH_*) is available for `mode` (0 patches, 1 frame) and `dtype`. */
 int zk_plan_has_path(const zk_plan* plan, int mode, int dtype, int path);
+/* 1 if the plan has the kernel behind zk_transform_points (ZK_OP_POINTS) / zk_frame_maps (ZK_OP_MAPS) for
+ * `dtype`: both need the row-separable tables and all moments of a unit in one pass, i.e. the full Zernike
+ * set with n_max <= 16.  (No reference counterpart: the reference composes these from ZPs.transform.) */
+#define ZK_OP_POINTS 1
+#define ZK_OP_MAPS   2
+int zk_plan_supports(const zk_plan* plan, int op, int dtype);
 /* Number of pixels inside the unit disk (rho <= 1 as evaluated by the caller's basis). */
 int zk_plan_disk_pixels(const zk_plan* plan);
 /* Force a kernel family (ZK_PATH_*); a forced path that is unavailable makes transforms fail. */

@@ -124,6 +124,7 @@ extern "C" void zk_plan_destroy(zk_plan* p) {
   if (p->d_gen_tab) (void)hipFree(p->d_gen_tab);
   if (p->d_in) (void)hipFree(p->d_in);
   if (p->d_out) (void)hipFree(p->d_out);
+  if (p->d_scratch) (void)hipFree(p->d_scratch);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
@@ -195,6 +196,15 @@ static int resolve_path(const zk_plan* p, int mode, int dtype, int64_t n_units =
 extern "C" int zk_plan_has_path(const zk_plan* p, int mode, int dtype, int path) {
   if (!p || (dtype != ZK_F32 && dtype != ZK_F64)) return 0;
   return (int)path_available(p, mode, dtype, path);
+}
+
+extern "C" int zk_plan_supports(const zk_plan* p, int op, int dtype) {
+  if (!p || (dtype != ZK_F32 && dtype != ZK_F64)) return 0;
+  switch (op) {
+    case ZK_OP_POINTS: return (int)zk_sep_points_available(p, dtype);
+    case ZK_OP_MAPS: return (int)zk_sep_maps_available(p, dtype);
+  }
+  return 0;
 }
 
 extern "C" int zk_plan_disk_pixels(const zk_plan* p) { return p ? p->npx : 0; }

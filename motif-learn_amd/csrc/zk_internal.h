@@ -44,6 +44,8 @@ struct zk_plan {
   size_t d_in_bytes = 0;
   double* d_out = nullptr;
   size_t d_out_bytes = 0;
+  double* d_scratch = nullptr;   // class-pass batch kernels (n_max > 16): [n_poly][chunk] planes
+  size_t d_scratch_bytes = 0;
 
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;  // pairs: [2k] start, [2k+1] stop
@@ -84,6 +86,8 @@ int zk_sep_build(zk_plan* p, const double* basis);   // fills p->sep or leaves i
 void zk_sep_free(zk_plan* p);
 bool zk_sep_frame_available(const zk_plan* p, int dtype);
 bool zk_sep_patches_available(const zk_plan* p, int dtype);
+bool zk_sep_points_available(const zk_plan* p, int dtype);  // single-pass kernels only (n_max <= 16)
+bool zk_sep_maps_available(const zk_plan* p, int dtype);
 int zk_launch_sep_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,
                         int64_t n_rows, double* out, hipStream_t s);
 int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,

@@ -95,13 +95,19 @@ struct zk_sep_pack {
   };
   static constexpr tables make() {
     tables t = {};
-    for (int s = 0; s < S::NP; ++s) {
-      t.deg[s] = S::slot_a(s) + S::slot_b(s);
-      t.zn[s] = Z::slot_n(s);
-    }
-    int o = 0;
-    for (int cls = 0; cls < 4; ++cls) {
-      const int b = S::cls_begin(cls), n = S::cls_count(cls);
+    int k = 0;  // same enumerations as zk_sep_set::slot_a / slot_b and zk_set::slot_n, done once
+    for (int cls = 0; cls < 4; ++cls)
+      for (int a = 0; a <= NMAX; ++a)
+        for (int b = 0; a + b <= NMAX; ++b)
+          if (S::cls_of(a, b) == cls) t.deg[k++] = a + b;
+    k = 0;
+    for (int cls = 0; cls < 4; ++cls)
+      for (int n = 0; n <= NMAX; ++n)
+        for (int m = -n; m <= n; m += 2)
+          if (Z::cls_of_m(m) == cls) t.zn[k++] = n;
+    int o = 0, b = 0;
+    for (int cls = 0; cls < 4; b += S::cls_count(cls), ++cls) {
+      const int n = S::cls_count(cls);
       for (int j = 0; j < n; ++j) {
         t.row_begin[b + j] = o;
         for (int i = 0; i < n; ++i) o += t.deg[b + i] <= t.zn[b + j];
@@ -114,16 +120,10 @@ struct zk_sep_pack {
 template <int NMAX>
 struct zk_sep_meta {
   static constexpr typename zk_sep_pack<NMAX>::tables tab = zk_sep_pack<NMAX>::make();
-  // position of entry (j, i) inside the packed row of j (valid when deg[i] <= zn[j]); slots are global
-  static constexpr int pos(int cls_begin, int j, int i) {
-    int k = 0;
-    for (int q = cls_begin; q < i; ++q) k += tab.deg[q] <= tab.zn[j];
-    return k;
-  }
 };
 
 #ifndef ZK_SEP_ROW
-#define ZK_SEP_ROW 24  // doubles per row of the P-value tables (degrees 0..16 used; rows start on 64-B lines)
+#define ZK_SEP_ROW 24  // doubles per row of the P-value tables (degrees 0..20 used; rows start on 64-B lines)
 #endif
 
 struct zk_sep_row {     // one quadrant row pair (r, K-1-r) with at least one disk pixel
@@ -214,9 +214,15 @@ struct zk_sep_tables {
 
 #ifdef __HIPCC__
 // Row sums of one row pair: S(a, parity of b) of zk_sep.h's header comment.
-template <int NMAX>
+// MASK (bit = parity class ZK_EE .. ZK_OO) restricts the object to some classes: class EE only needs the
+// fold ee and the sums SEp, OE: oe / SOp, EO: eo / SEm, OO: oo / SOm, and T is block-diagonal in the
+// classes -- so the moments of a class can be computed by a pass of their own, with a quarter of the
+// accumulators (n_max > 16, where the full set no longer fits a lane's registers).
+template <int NMAX, int MASK = 15>
 struct zk_sep_rows {
   using S = zk_sep_set<NMAX>;
+  static constexpr bool kEE = MASK & (1 << ZK_EE), kOE = MASK & (1 << ZK_OE), kEO = MASK & (1 << ZK_EO),
+                        kOO = MASK & (1 << ZK_OO);
   double SEp[S::NE], SEm[S::NE], SOp[S::NO > 0 ? S::NO : 1], SOm[S::NO > 0 ? S::NO : 1];
 
   __device__ __forceinline__ void clear_row() {
@@ -231,13 +237,13 @@ struct zk_sep_rows {
     const double ee = s1 + s2, oe = d1 + d2, eo = s1 - s2, oo = d1 - d2;
 #pragma unroll
     for (int i = 0; i < S::NE; ++i) {
-      SEp[i] = __builtin_fma(ee, px[2 * i], SEp[i]);
-      SEm[i] = __builtin_fma(eo, px[2 * i], SEm[i]);
+      if constexpr (kEE) SEp[i] = __builtin_fma(ee, px[2 * i], SEp[i]);
+      if constexpr (kEO) SEm[i] = __builtin_fma(eo, px[2 * i], SEm[i]);
     }
 #pragma unroll
     for (int i = 0; i < S::NO; ++i) {
-      SOp[i] = __builtin_fma(oe, px[2 * i + 1], SOp[i]);
-      SOm[i] = __builtin_fma(oo, px[2 * i + 1], SOm[i]);
+      if constexpr (kOE) SOp[i] = __builtin_fma(oe, px[2 * i + 1], SOp[i]);
+      if constexpr (kOO) SOm[i] = __builtin_fma(oo, px[2 * i + 1], SOm[i]);
     }
   }
   // Row-at-a-time form (zk_sep_patches.hip): one pixel a and its column mirror b of a SINGLE row.  The
@@ -274,10 +280,10 @@ struct zk_sep_rows {
   }
 };
 
-template <int NMAX>
-struct zk_sep_acc : zk_sep_rows<NMAX> {
+template <int NMAX, int MASK = 15>
+struct zk_sep_acc : zk_sep_rows<NMAX, MASK> {
   using S = zk_sep_set<NMAX>;
-  using R = zk_sep_rows<NMAX>;
+  using R = zk_sep_rows<NMAX, MASK>;
   double M[S::NP];
 
   __device__ __forceinline__ void clear_all() {
@@ -292,9 +298,11 @@ struct zk_sep_acc : zk_sep_rows<NMAX> {
   template <int s>
   __device__ __forceinline__ void slot_fma(const R& rs, const ZK_CONST double* py) {
     constexpr int a = S::slot_a(s), b = S::slot_b(s);
-    const double v = (a & 1) ? ((b & 1) ? rs.SOm[a >> 1] : rs.SOp[a >> 1])
-                             : ((b & 1) ? rs.SEm[a >> 1] : rs.SEp[a >> 1]);
-    M[s] = __builtin_fma(py[b], v, M[s]);
+    if constexpr ((MASK >> S::cls_of(a, b)) & 1) {
+      const double v = (a & 1) ? ((b & 1) ? rs.SOm[a >> 1] : rs.SOp[a >> 1])
+                               : ((b & 1) ? rs.SEm[a >> 1] : rs.SEp[a >> 1]);
+      M[s] = __builtin_fma(py[b], v, M[s]);
+    }
   }
   template <int... Is>
   __device__ __forceinline__ void row_all(const R& rs, const ZK_CONST double* py, std::integer_sequence<int, Is...>) {
@@ -334,26 +342,17 @@ struct zk_sep_acc : zk_sep_rows<NMAX> {
   // each finished moment; `slot` is a std::integral_constant, so callers can use it both as an int
   // and (decltype(slot)::value) as a compile-time constant.  The T table holds the packed rows of
   // zk_sep_pack (entries with a + b <= n_j only).
-  template <int JS, int I>
-  __device__ __forceinline__ void transform_term(const ZK_CONST double* tb, double& z) {
-    using P = zk_sep_meta<NMAX>;
-    constexpr int cb = S::cls_begin(S::cls_of(S::slot_a(JS), S::slot_b(JS)));
-    if constexpr (P::tab.deg[cb + I] <= P::tab.zn[JS]) {
-      constexpr int k = P::pos(cb, JS, cb + I);
-      z = __builtin_fma(tb[k], M[cb + I], z);
-    }
-  }
-  template <int JS, int... Is>
-  __device__ __forceinline__ void transform_terms(const ZK_CONST double* tb, double& z, std::integer_sequence<int, Is...>) {
-    (transform_term<JS, Is>(tb, z), ...);
-  }
   template <int CLS, int J, typename F>
   __device__ __forceinline__ void transform_row(const ZK_CONST double* tmat, F&& emit) {
+    using P = zk_sep_meta<NMAX>;
     constexpr int n = S::cls_count(CLS), off = S::cls_begin(CLS);
-    constexpr int rb = zk_sep_meta<NMAX>::tab.row_begin[off + J];
+    constexpr int rb = P::tab.row_begin[off + J], zn = P::tab.zn[off + J];
     const ZK_CONST double* tb = tmat + rb;
     double z = 0.0;
-    transform_terms<off + J>(tb, z, std::make_integer_sequence<int, n>{});
+    int k = 0;  // position in the packed row; the loop is fully unrolled, so k and the test fold away
+#pragma unroll
+    for (int i = 0; i < n; ++i)
+      if (P::tab.deg[off + i] <= zn) z = __builtin_fma(tb[k++], M[off + i], z);
     emit(std::integral_constant<int, off + J>{}, z);
     // keep the scheduler from hoisting every row's scalar loads to the top (hundreds of SGPRs)
     __builtin_amdgcn_sched_barrier(0);
@@ -377,10 +376,10 @@ struct zk_sep_acc : zk_sep_rows<NMAX> {
   }
   template <typename F>
   __device__ __forceinline__ void transform(const ZK_CONST double* tmat, F&& emit) {
-    transform_class<ZK_EE>(tmat, emit);
-    transform_class<ZK_OE>(tmat, emit);
-    transform_class<ZK_EO>(tmat, emit);
-    transform_class<ZK_OO>(tmat, emit);
+    if constexpr (R::kEE) transform_class<ZK_EE>(tmat, emit);
+    if constexpr (R::kOE) transform_class<ZK_OE>(tmat, emit);
+    if constexpr (R::kEO) transform_class<ZK_EO>(tmat, emit);
+    if constexpr (R::kOO) transform_class<ZK_OO>(tmat, emit);
   }
 };
 
@@ -432,8 +431,8 @@ __device__ __forceinline__ void zk_batch_store_rows(const double (&z)[NP], const
 // (row r) and `bot` (row K-1-r).  Two pixels per iteration through four running pointers, so the loop
 // spends 4 integer adds per 2 pixels on addressing and the second pixel's LDS reads and scalar row
 // overlap the first pixel's FMAs.
-template <int NMAX>
-__device__ __forceinline__ void zk_sep_row_pair(zk_sep_acc<NMAX>& acc, const double* __restrict__ top,
+template <int NMAX, int MASK>
+__device__ __forceinline__ void zk_sep_row_pair(zk_sep_acc<NMAX, MASK>& acc, const double* __restrict__ top,
                                                 const double* __restrict__ bot, int cmin, int Q, int K,
                                                 const ZK_CONST double* px) {
   const double* tf = top + cmin;

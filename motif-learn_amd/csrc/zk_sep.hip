@@ -8,7 +8,7 @@
 
 typedef long double ld;
 
-static const int kSepNmax[] = {4, 6, 8, 10, 12, 14, 16};  // instantiated kernels
+static const int kSepNmax[] = {4, 6, 8, 10, 12, 14, 16, 20};  // instantiated kernels (20: one pass per parity class)
 
 // x^a = sum_i L[a][i] P_i(x), from x P_i = ((i+1) P_{i+1} + i P_{i-1}) / (2i+1); all terms positive.
 static std::vector<std::vector<ld>> monomial_to_legendre(int deg) {
@@ -147,6 +147,10 @@ int zk_sep_build(zk_plan* p, const double* basis) {
     if (cmin < Q) rows.push_back({r, cmin});
   }
   if (rows.empty()) return 0;
+  // The kernels use the exact polynomial; the caller's float64 basis carries the rounding of the reference's
+  // factorial sums (_zps.py:52-64), ~2e-11 of max|V| at n_max 16, ~1e-9 at 20 and ~3e-8 at 24 -- so the
+  // substitution stops at 20, where the two still agree to a few 1e-9.
+  const ld tol = n_max <= 16 ? 1e-9L : 4e-9L;
   for (int j = 0; j < NP; ++j) {
     double vmax = 0.0;
     for (int t = 0; t < K * K; ++t) vmax = std::max(vmax, fabs(basis[(size_t)j * K * K + t]));
@@ -157,7 +161,7 @@ int zk_sep_build(zk_plan* p, const double* basis) {
         for (int a = 0; a <= knm; ++a)
           for (int b = 0; a + b <= knm; ++b)
             v += Tfull[((size_t)j * D + a) * D + b] * P[(size_t)c * D + a] * P[(size_t)r * D + b];
-        if (fabsl(v - (ld)basis[((size_t)j * K + r) * K + c]) > 1e-9L * (ld)vmax + 1e-300L) return 0;
+        if (fabsl(v - (ld)basis[((size_t)j * K + r) * K + c]) > tol * (ld)vmax + 1e-300L) return 0;
       }
   }
 
@@ -226,10 +230,10 @@ int zk_sep_build(zk_plan* p, const double* basis) {
     const int es = dt == 0 ? 4 : 8, UP = 64 / es;
     if (K < UP) continue;  // (rows need not be 16-B aligned: LDS-DMA sources only need element alignment)
     zk_sep_tables::batch_tables& bt = t->batch[dt];
-    bt.run = (dt == 0 && K == 32) ? 8 : 4;
+    bt.run = (dt == 0 && K == 32 && knm <= 16) ? 8 : 4;  // class-pass kernels (n_max > 16) only use 64-B runs
     std::vector<zk_sep_unit> units;
     const int LW = 128 / es;  // pixels per 128-B line: 32 float32, 16 float64
-    if (K % (2 * LW) == 0) {
+    if (K % (2 * LW) == 0 && knm <= 16) {
       // Wide patches (float32 K % 64 == 0, float64 K % 32 == 0): the quadrant of a row is a whole number
       // of 128-B lines, so a unit is one line of quadrant columns of ONE row -- (y, c0..c0+LW-1) -- and
       // its mirror line, and the two rows of a pair are consumed one after the other
@@ -311,7 +315,7 @@ int zk_sep_build(zk_plan* p, const double* basis) {
     for (int dt = 0; dt < 2; ++dt) {
       const int es = dt == 0 ? 4 : 8, LW = 128 / es;
       const long long patch_bytes = (long long)K * K * es;
-      if (K < 8 || K > 1024) continue;
+      if (K < 8 || K > 1024 || knm > 16) continue;
       // granules that would cross the end of a patch are clamped back into it (their content is then
       // misplaced), so every disk pixel must lie in the granules below that point
       if ((long long)(srows[n_srows - 1].te + 1) * es > patch_bytes / 16 * 16) continue;

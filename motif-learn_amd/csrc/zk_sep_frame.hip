@@ -10,9 +10,23 @@
 // Roofline: FP64-VALU-bound; algorithmic HBM bytes s_in + 8 N_poly per pixel.
 #include "zk_sep.h"
 
+// Build groups: the kernel instances are spread over several translation units (Makefile) so that they
+// compile in parallel: group 0 = n_max kernels 4..12 (and every non-template entry point), 1 = 14 / 16,
+// 2 = 20 (class-pass kernels).  Group 0's launcher forwards to the others.
+#ifndef ZK_NMAX_GROUP
+#define ZK_NMAX_GROUP 0
+#endif
+#if ZK_NMAX_GROUP == 0
+#define ZK_GROUP_FN(name) name
+#elif ZK_NMAX_GROUP == 1
+#define ZK_GROUP_FN(name) name##_g1
+#else
+#define ZK_GROUP_FN(name) name##_g2
+#endif
+
 namespace {
 
-template <int NMAX, typename T>
+template <int NMAX, typename T, int MASK>
 __global__ __launch_bounds__(256) void zk_frame_sep_kernel(
     const T* __restrict__ img, double* __restrict__ out, const zk_sep_row* __restrict__ rows,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
@@ -37,7 +51,7 @@ __global__ __launch_bounds__(256) void zk_frame_sep_kernel(
   }
   __syncthreads();
 
-  zk_sep_acc<NMAX> acc;
+  zk_sep_acc<NMAX, MASK> acc;  // MASK: the parity classes this launch computes (all, or one per pass)
   acc.clear_all();
   const double* __restrict__ mine = tile + wave * tile_pitch + lane;
   const ZK_CONST int32_t* rtab = zk_const((const int32_t*)rows);
@@ -63,12 +77,12 @@ __global__ __launch_bounds__(256) void zk_frame_sep_kernel(
   });
 }
 
-template <int NMAX, typename T>
+template <int NMAX, typename T, int MASK = 15>
 int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out,
                hipStream_t s) {
   const zk_sep_tables* t = p->sep;
   const size_t lds = (size_t)(p->size + 3) * t->tile_pitch * sizeof(double);
-  auto kern = zk_frame_sep_kernel<NMAX, T>;
+  auto kern = zk_frame_sep_kernel<NMAX, T, MASK>;
   if (lds > 64 * 1024)
     ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if ((n_rows + 3) / 4 > 65535) return zk_fail(ZK_E_BADARG, "more than 262140 output rows per call: split the row band");
@@ -81,31 +95,60 @@ int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, i
   return zk_prof_end(p, s);
 }
 
+// n_max > 16: one launch per parity class (a quarter of the accumulators each; every launch writes the
+// output planes of its own class)
+template <int NMAX, typename T>
+int launch_passes(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out,
+                  hipStream_t s) {
+  int rc = launch_one<NMAX, T, 1 << ZK_EE>(p, in, H, W, row0, n_rows, out, s);
+  if (!rc) rc = launch_one<NMAX, T, 1 << ZK_OE>(p, in, H, W, row0, n_rows, out, s);
+  if (!rc) rc = launch_one<NMAX, T, 1 << ZK_EO>(p, in, H, W, row0, n_rows, out, s);
+  if (!rc) rc = launch_one<NMAX, T, 1 << ZK_OO>(p, in, H, W, row0, n_rows, out, s);
+  return rc;
+}
+
 template <typename T>
 int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out,
              hipStream_t s) {
   switch (p->sep->kernel_nmax) {
+#if ZK_NMAX_GROUP == 0
     case 4: return launch_one<4, T>(p, in, H, W, row0, n_rows, out, s);
     case 6: return launch_one<6, T>(p, in, H, W, row0, n_rows, out, s);
     case 8: return launch_one<8, T>(p, in, H, W, row0, n_rows, out, s);
     case 10: return launch_one<10, T>(p, in, H, W, row0, n_rows, out, s);
     case 12: return launch_one<12, T>(p, in, H, W, row0, n_rows, out, s);
+#endif
+#if ZK_NMAX_GROUP == 1
     case 14: return launch_one<14, T>(p, in, H, W, row0, n_rows, out, s);
     case 16: return launch_one<16, T>(p, in, H, W, row0, n_rows, out, s);
+#endif
+#if ZK_NMAX_GROUP == 2
+    case 20: return launch_passes<20, T>(p, in, H, W, row0, n_rows, out, s);
+#endif
   }
   return zk_fail(ZK_E_BADARG, "no separable frame kernel for this n_max");
 }
 
 }  // namespace
 
+#if ZK_NMAX_GROUP == 0
 bool zk_sep_frame_available(const zk_plan* p, int dtype) {
   (void)dtype;
   if (!p->sep || p->sep->n_rows == 0) return false;
   return (size_t)(p->size + 3) * p->sep->tile_pitch * sizeof(double) <= 160 * 1024;
 }
+int zk_launch_sep_frame_g1(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                           double* out, hipStream_t s);
+int zk_launch_sep_frame_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                           double* out, hipStream_t s);
+#endif
 
-int zk_launch_sep_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
-                        double* out, hipStream_t s) {
+int ZK_GROUP_FN(zk_launch_sep_frame)(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,
+                                     int64_t n_rows, double* out, hipStream_t s) {
+#if ZK_NMAX_GROUP == 0
+  if (p->sep->kernel_nmax > 16) return zk_launch_sep_frame_g2(p, in, dtype, H, W, row0, n_rows, out, s);
+  if (p->sep->kernel_nmax > 12) return zk_launch_sep_frame_g1(p, in, dtype, H, W, row0, n_rows, out, s);
+#endif
   if (dtype == ZK_F32) return launch_t<float>(p, in, H, W, row0, n_rows, out, s);
   return launch_t<double>(p, in, H, W, row0, n_rows, out, s);
 }

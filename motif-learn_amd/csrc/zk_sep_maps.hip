@@ -18,6 +18,20 @@
 
 #include "zk_sep.h"
 
+// Build groups: the kernel instances are spread over several translation units (Makefile) so that they
+// compile in parallel: group 0 = n_max kernels 4..12 (and every non-template entry point), 1 = 14 / 16,
+// 2 = 20 (class-pass kernels).  Group 0's launcher forwards to the others.
+#ifndef ZK_NMAX_GROUP
+#define ZK_NMAX_GROUP 0
+#endif
+#if ZK_NMAX_GROUP == 0
+#define ZK_GROUP_FN(name) name
+#elif ZK_NMAX_GROUP == 1
+#define ZK_GROUP_FN(name) name##_g1
+#else
+#define ZK_GROUP_FN(name) name##_g2
+#endif
+
 #define ZK_MAX_FOLDS 8
 // waves per SIMD the register allocator is asked to fit (launch bound)
 #ifndef ZK_MAPS_WAVES
@@ -207,23 +221,44 @@ template <typename T>
 int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
              const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror, hipStream_t s) {
   switch (p->sep->kernel_nmax) {
+#if ZK_NMAX_GROUP == 0
     case 4: return launch_one<4, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
     case 6: return launch_one<6, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
     case 8: return launch_one<8, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
     case 10: return launch_one<10, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
     case 12: return launch_one<12, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+#endif
+#if ZK_NMAX_GROUP == 1
     case 14: return launch_one<14, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
     case 16: return launch_one<16, T>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+#endif
   }
   return zk_fail(ZK_E_BADARG, "no fused maps kernel for this n_max");
 }
 
 }  // namespace
 
+// the kernel launch proper, per build group (the host-side preparation below lives in group 0)
+int ZK_GROUP_FN(zk_maps_dispatch)(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                                  const zk_maps_params& prm, const double* d_trig, double* rot, double* ab,
+                                  double* mirror, hipStream_t s) {
+  if (dtype == ZK_F32) return launch_t<float>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+  return launch_t<double>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+}
+
+#if ZK_NMAX_GROUP == 0
+int zk_maps_dispatch_g1(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                        const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
+                        hipStream_t s);
+
+bool zk_sep_maps_available(const zk_plan* p, int dtype) {
+  return zk_sep_frame_available(p, dtype) && p->sep->kernel_nmax <= 16;  // needs all classes in one pass
+}
+
 int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                        const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
                        const double* theta, int n_theta, double* rot, double* ab, double* mirror, hipStream_t s) {
-  if (!zk_sep_frame_available(p, dtype))
+  if (!zk_sep_maps_available(p, dtype))
     return zk_fail(ZK_E_BADARG, "plan has no fused maps kernel (needs the separable tables: n_max <= 16)");
   if (n_folds < 0 || n_folds > ZK_MAX_FOLDS) return zk_fail(ZK_E_BADARG, "at most 8 folds per call");
   if (p_norm != 0 && p_norm != 2) return zk_fail(ZK_E_BADARG, "p must be 2 or 0 (None)");
@@ -281,7 +316,7 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
   // stream-ordered upload from a pageable stack-lifetime buffer: synchronise before it goes away
   ZK_HIP(hipMemcpyAsync(t->d_trig, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
   ZK_HIP(hipStreamSynchronize(s));
-  if (dtype == ZK_F32)
-    return launch_t<float>(p, in, H, W, row0, n_rows, prm, p->sep->d_trig, rot, ab, mirror, s);
-  return launch_t<double>(p, in, H, W, row0, n_rows, prm, p->sep->d_trig, rot, ab, mirror, s);
+  if (knm > 12) return zk_maps_dispatch_g1(p, in, dtype, H, W, row0, n_rows, prm, t->d_trig, rot, ab, mirror, s);
+  return zk_maps_dispatch(p, in, dtype, H, W, row0, n_rows, prm, t->d_trig, rot, ab, mirror, s);
 }
+#endif

@@ -1,6 +1,7 @@
 // zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157): HBM-streaming,
 // LDS-DMA transposed, row-separable arithmetic.  float32 patches of any size K >= 16 and float64 patches
-// of any size K >= 8, odd sizes included (LDS-DMA sources only need element alignment); n_max <= 16.
+// of any size K >= 8, odd sizes included (LDS-DMA sources only need element alignment); n_max <= 20
+// (17-20: one launch per mirror-parity class, see MASK below).
 // (Large batches of sizes that get no whole-line units here go to zk_sep_stream.hip under ZK_PATH_AUTO.)
 //
 // Work decomposition.  One wave owns 64 consecutive patches, one patch per lane, and keeps that
@@ -38,6 +39,20 @@
 // Roofline: algorithmic bytes K*K*s + 8*N_poly per patch (4 456 B at float32 (32, 8)); HBM-bound.
 #include "zk_sep.h"
 
+// Build groups: the kernel instances are spread over several translation units (Makefile) so that they
+// compile in parallel: group 0 = n_max kernels 4..12 (and every non-template entry point), 1 = 14 / 16,
+// 2 = 20 (class-pass kernels).  Group 0's launcher forwards to the others.
+#ifndef ZK_NMAX_GROUP
+#define ZK_NMAX_GROUP 0
+#endif
+#if ZK_NMAX_GROUP == 0
+#define ZK_GROUP_FN(name) name
+#elif ZK_NMAX_GROUP == 1
+#define ZK_GROUP_FN(name) name##_g1
+#else
+#define ZK_GROUP_FN(name) name##_g2
+#endif
+
 // Unit-order rotation.  Waves start together and walk the same unit list, so at any instant nearly all
 // 2048 resident waves would be fetching the SAME row pair of their patches: addresses that agree in bits
 // 7..11, i.e. a fraction of the HBM channels at a time (the kernel time then moves by ~9 % with the
@@ -53,8 +68,11 @@ namespace {
 #define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int NMAX, int RUN, typename TIN, bool WIDE>
-__global__ __launch_bounds__(256, (NMAX <= 10 ? 2 : 1)) void zk_patch_sep_kernel(
+// MASK: the parity classes this launch computes -- all of them (15), or one class per launch for
+// n_max > 16 (zk_sep.h); a class pass writes its moments as planes of a scratch matrix [column][patch]
+// (coalesced over the lanes), which zk_transpose_kernel turns into the (N, n_poly) rows afterwards.
+template <int NMAX, int RUN, typename TIN, bool WIDE, int MASK = 15>
+__global__ __launch_bounds__(256, ((NMAX <= 10 || MASK != 15) ? 2 : 1)) void zk_patch_sep_kernel(
     const TIN* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
     int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp, const int32_t* __restrict__ row_starts,
@@ -109,7 +127,7 @@ __global__ __launch_bounds__(256, (NMAX <= 10 ? 2 : 1)) void zk_patch_sep_kernel
 #pragma unroll
   for (int g = 0; g < RUN; ++g) rd[g] = (lane * RUN + ((g + (lane >> SH)) & (RUN - 1))) * 4;
 
-  zk_sep_acc<NMAX> acc;
+  zk_sep_acc<NMAX, MASK> acc;
   acc.clear_all();
   const ZK_CONST double* px = zk_const(xq);
 
@@ -227,15 +245,38 @@ __global__ __launch_bounds__(256, (NMAX <= 10 ? 2 : 1)) void zk_patch_sep_kernel
     }
   }
 
-  // ---- Z = T M, then (patch, column) rows via LDS -> 16-B stores ------------------------------------
-  double z[S::NP];
-  acc.transform(zk_const(tmat), [&](auto slot, double v) { z[slot] = v; });
   const ZK_CONST int32_t* cmap = zk_const(colmap);
-  // ppp = patches per pass (host: largest power of two with ppp * n_poly <= 2048)
-  zk_batch_store_rows<S::NP>(z, cmap, (double*)wl, out + patch0 * n_poly, lane, nv, n_poly, ppp);
+  if constexpr (MASK == 15) {
+    // ---- Z = T M, then (patch, column) rows via LDS -> 16-B stores ----------------------------------
+    double z[S::NP];
+    acc.transform(zk_const(tmat), [&](auto slot, double v) { z[slot] = v; });
+    // ppp = patches per pass (host: largest power of two with ppp * n_poly <= 2048)
+    zk_batch_store_rows<S::NP>(z, cmap, (double*)wl, out + patch0 * n_poly, lane, nv, n_poly, ppp);
+  } else {
+    // ---- class pass: `out` is the scratch matrix, plane stride n_patches ------------------------------
+    double* const sp = out + patch0 + lane;
+    acc.transform(zk_const(tmat), [&](auto slot, double v) {
+      const int col = cmap[slot];
+      if (col >= 0 && lane < nv) sp[(long long)col * n_patches] = v;
+    });
+  }
 }
 
-template <int NMAX, int RUN, typename TIN, bool WIDE>
+// in[c * n + p] -> out[p * n_poly + c]: the class passes' scratch planes to (N, n_poly) rows
+__global__ __launch_bounds__(256) void zk_transpose_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                           int n_poly, long long n) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long p0 = (long long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < n_poly && p0 + tx < n) tile[j][tx] = in[(long long)(c0 + j) * n + p0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (p0 + j < n && c0 + tx < n_poly) out[(p0 + j) * n_poly + c0 + tx] = tile[tx][j];
+}
+
+template <int NMAX, int RUN, typename TIN, bool WIDE, int MASK = 15>
 int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
   const zk_sep_tables* t = p->sep;
   const zk_sep_tables::batch_tables& bt = t->batch[sizeof(TIN) == 4 ? 0 : 1];
@@ -246,28 +287,70 @@ int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
   while (ppp * p->n_poly > 2048) ppp >>= 1;
   int rc = zk_prof_begin(p, s);
   if (rc) return rc;
-  hipLaunchKernelGGL((zk_patch_sep_kernel<NMAX, RUN, TIN, WIDE>), dim3((unsigned)blocks), dim3(256), 0, s, (const TIN*)in,
+  hipLaunchKernelGGL((zk_patch_sep_kernel<NMAX, RUN, TIN, WIDE, MASK>), dim3((unsigned)blocks), dim3(256), 0, s, (const TIN*)in,
                      out, bt.d_units, t->d_xq, t->d_T, t->d_colmap, bt.n_units, p->n_poly, (long long)n_patches,
                      p->size * p->size * (int)sizeof(TIN), ppp, bt.d_row_starts, ZK_ROTATE ? bt.n_row_starts : 0);
   ZK_HIP(hipGetLastError());
   return zk_prof_end(p, s);
 }
 
+#if ZK_NMAX_GROUP == 2
+// n_max > 16: per chunk of patches, one launch per parity class into the plan's scratch planes, then the
+// transposition into the caller's rows (64-B-run units only: these sizes are bound by arithmetic)
+template <int NMAX, typename TIN>
+int launch_passes(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
+  const int64_t chunk_max = 1 << 18;
+  const size_t need = (size_t)(n_patches < chunk_max ? n_patches : chunk_max) * p->n_poly * sizeof(double);
+  if (p->d_scratch_bytes < need) {
+    if (p->d_scratch) ZK_HIP(hipFree(p->d_scratch));
+    p->d_scratch = nullptr;
+    p->d_scratch_bytes = 0;
+    ZK_HIP(hipMalloc((void**)&p->d_scratch, need));
+    p->d_scratch_bytes = need;
+  }
+  const size_t patch_elems = (size_t)p->size * p->size;
+  for (int64_t first = 0; first < n_patches; first += chunk_max) {
+    const int64_t n = n_patches - first < chunk_max ? n_patches - first : chunk_max;
+    const TIN* src = (const TIN*)in + first * patch_elems;
+    int rc = launch_one<NMAX, 4, TIN, false, 1 << ZK_EE>(p, src, n, p->d_scratch, s);
+    if (!rc) rc = launch_one<NMAX, 4, TIN, false, 1 << ZK_OE>(p, src, n, p->d_scratch, s);
+    if (!rc) rc = launch_one<NMAX, 4, TIN, false, 1 << ZK_EO>(p, src, n, p->d_scratch, s);
+    if (!rc) rc = launch_one<NMAX, 4, TIN, false, 1 << ZK_OO>(p, src, n, p->d_scratch, s);
+    if (rc) return rc;
+    if ((rc = zk_prof_begin(p, s))) return rc;
+    hipLaunchKernelGGL(zk_transpose_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((p->n_poly + 31) / 32)), dim3(256), 0,
+                       s, p->d_scratch, out + first * p->n_poly, p->n_poly, (long long)n);
+    ZK_HIP(hipGetLastError());
+    if ((rc = zk_prof_end(p, s))) return rc;
+  }
+  return 0;
+}
+
+#else
 template <int RUN, typename TIN, bool WIDE = false>
 int launch_run(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
   switch (p->sep->kernel_nmax) {
+#if ZK_NMAX_GROUP == 0
     case 4: return launch_one<4, RUN, TIN, WIDE>(p, in, n_patches, out, s);
     case 6: return launch_one<6, RUN, TIN, WIDE>(p, in, n_patches, out, s);
     case 8: return launch_one<8, RUN, TIN, WIDE>(p, in, n_patches, out, s);
     case 10: return launch_one<10, RUN, TIN, WIDE>(p, in, n_patches, out, s);
     case 12: return launch_one<12, RUN, TIN, WIDE>(p, in, n_patches, out, s);
+#endif
+#if ZK_NMAX_GROUP == 1
     case 14: return launch_one<14, RUN, TIN, WIDE>(p, in, n_patches, out, s);
     case 16: return launch_one<16, RUN, TIN, WIDE>(p, in, n_patches, out, s);
+#endif
   }
   return zk_fail(ZK_E_BADARG, "no batch kernel for this n_max");
 }
+#endif
 
 }  // namespace
+
+#if ZK_NMAX_GROUP == 0
+int zk_launch_sep_patches_g1(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s);
+int zk_launch_sep_patches_g2(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s);
 
 bool zk_sep_patches_available(const zk_plan* p, int dtype) {
   const zk_sep_tables* t = p->sep;
@@ -275,13 +358,25 @@ bool zk_sep_patches_available(const zk_plan* p, int dtype) {
   return t && t->batch[dtype == ZK_F32 ? 0 : 1].n_units > 0 && p->n_poly <= 1024 && p->size <= 1024;
 }
 
-int zk_launch_sep_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {
+#endif
+
+int ZK_GROUP_FN(zk_launch_sep_patches)(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,
+                                       hipStream_t s) {
+#if ZK_NMAX_GROUP == 0
   if (((uintptr_t)in & (dtype == ZK_F32 ? 3 : 7)) || ((uintptr_t)out & 15))  // element-aligned DMA, 16-B stores
     return zk_launch_generic_patches(p, in, dtype, n_patches, out, s);
+  if (p->sep->kernel_nmax > 16) return zk_launch_sep_patches_g2(p, in, dtype, n_patches, out, s);
+  if (p->sep->kernel_nmax > 12) return zk_launch_sep_patches_g1(p, in, dtype, n_patches, out, s);
+#endif
+#if ZK_NMAX_GROUP == 2
+  if (dtype == ZK_F32) return launch_passes<20, float>(p, in, n_patches, out, s);
+  return launch_passes<20, double>(p, in, n_patches, out, s);
+#else
   if (dtype == ZK_F64)
     return p->sep->batch[1].wide ? launch_run<8, double, true>(p, in, n_patches, out, s)
                                  : launch_run<4, double>(p, in, n_patches, out, s);
   if (p->sep->batch[0].wide) return launch_run<8, float, true>(p, in, n_patches, out, s);
   return p->sep->batch[0].run == 8 ? launch_run<8, float>(p, in, n_patches, out, s)
                                    : launch_run<4, float>(p, in, n_patches, out, s);
+#endif
 }

@@ -11,6 +11,20 @@
 // HBM traffic is 8 B of coordinates in and 8 N_poly B out per point.
 #include "zk_sep.h"
 
+// Build groups: the kernel instances are spread over several translation units (Makefile) so that they
+// compile in parallel: group 0 = n_max kernels 4..12 (and every non-template entry point), 1 = 14 / 16,
+// 2 = 20 (class-pass kernels).  Group 0's launcher forwards to the others.
+#ifndef ZK_NMAX_GROUP
+#define ZK_NMAX_GROUP 0
+#endif
+#if ZK_NMAX_GROUP == 0
+#define ZK_GROUP_FN(name) name
+#elif ZK_NMAX_GROUP == 1
+#define ZK_GROUP_FN(name) name##_g1
+#else
+#define ZK_GROUP_FN(name) name##_g2
+#endif
+
 namespace {
 
 template <int NMAX, typename T>
@@ -67,22 +81,39 @@ template <typename T>
 int launch_t(zk_plan* p, const void* img, const int32_t* pts, int64_t H, int64_t W, int64_t n_points, double* out,
              hipStream_t s) {
   switch (p->sep->kernel_nmax) {
+#if ZK_NMAX_GROUP == 0
     case 4: return launch_one<4, T>(p, img, pts, H, W, n_points, out, s);
     case 6: return launch_one<6, T>(p, img, pts, H, W, n_points, out, s);
     case 8: return launch_one<8, T>(p, img, pts, H, W, n_points, out, s);
     case 10: return launch_one<10, T>(p, img, pts, H, W, n_points, out, s);
     case 12: return launch_one<12, T>(p, img, pts, H, W, n_points, out, s);
+#endif
+#if ZK_NMAX_GROUP == 1
     case 14: return launch_one<14, T>(p, img, pts, H, W, n_points, out, s);
     case 16: return launch_one<16, T>(p, img, pts, H, W, n_points, out, s);
+#endif
   }
   return zk_fail(ZK_E_BADARG, "no point kernel for this n_max");
 }
 
 }  // namespace
 
-int zk_launch_sep_points(zk_plan* p, const void* img, int dtype, int64_t H, int64_t W, const int32_t* pts,
-                         int64_t n_points, double* out, hipStream_t s) {
-  if (!p->sep || p->sep->n_rows == 0) return zk_fail(ZK_E_BADARG, "plan has no separable tables");
+#if ZK_NMAX_GROUP == 0
+bool zk_sep_points_available(const zk_plan* p, int dtype) {
+  (void)dtype;
+  return p->sep && p->sep->n_rows > 0 && p->sep->kernel_nmax <= 16;
+}
+int zk_launch_sep_points_g1(zk_plan* p, const void* img, int dtype, int64_t H, int64_t W, const int32_t* pts,
+                            int64_t n_points, double* out, hipStream_t s);
+#endif
+
+int ZK_GROUP_FN(zk_launch_sep_points)(zk_plan* p, const void* img, int dtype, int64_t H, int64_t W, const int32_t* pts,
+                                      int64_t n_points, double* out, hipStream_t s) {
+#if ZK_NMAX_GROUP == 0
+  if (!zk_sep_points_available(p, dtype))
+    return zk_fail(ZK_E_BADARG, "plan has no key-point kernel (needs the separable tables and n_max <= 16)");
+  if (p->sep->kernel_nmax > 12) return zk_launch_sep_points_g1(p, img, dtype, H, W, pts, n_points, out, s);
+#endif
   if (dtype == ZK_F32) return launch_t<float>(p, img, pts, H, W, n_points, out, s);
   return launch_t<double>(p, img, pts, H, W, n_points, out, s);
 }

@@ -26,6 +26,20 @@
 // Roofline: algorithmic bytes K*K*s + 8*N_poly per patch; HBM-bound.
 #include "zk_sep.h"
 
+// Build groups: the kernel instances are spread over several translation units (Makefile) so that they
+// compile in parallel: group 0 = n_max kernels 4..12 (and every non-template entry point), 1 = 14 / 16,
+// 2 = 20 (class-pass kernels).  Group 0's launcher forwards to the others.
+#ifndef ZK_NMAX_GROUP
+#define ZK_NMAX_GROUP 0
+#endif
+#if ZK_NMAX_GROUP == 0
+#define ZK_GROUP_FN(name) name
+#elif ZK_NMAX_GROUP == 1
+#define ZK_GROUP_FN(name) name##_g1
+#else
+#define ZK_GROUP_FN(name) name##_g2
+#endif
+
 namespace {
 
 #define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -227,18 +241,25 @@ int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
 template <typename TIN>
 int launch_t(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
   switch (p->sep->kernel_nmax) {
+#if ZK_NMAX_GROUP == 0
     case 4: return launch_one<4, TIN>(p, in, n_patches, out, s);
     case 6: return launch_one<6, TIN>(p, in, n_patches, out, s);
     case 8: return launch_one<8, TIN>(p, in, n_patches, out, s);
     case 10: return launch_one<10, TIN>(p, in, n_patches, out, s);
     case 12: return launch_one<12, TIN>(p, in, n_patches, out, s);
+#endif
+#if ZK_NMAX_GROUP == 1
     case 14: return launch_one<14, TIN>(p, in, n_patches, out, s);
     case 16: return launch_one<16, TIN>(p, in, n_patches, out, s);
+#endif
   }
   return zk_fail(ZK_E_BADARG, "no stream batch kernel for this n_max");
 }
 
 }  // namespace
+
+#if ZK_NMAX_GROUP == 0
+int zk_launch_sep_stream_g1(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s);
 
 bool zk_sep_stream_available(const zk_plan* p, int dtype) {
   const zk_sep_tables* t = p->sep;
@@ -253,7 +274,13 @@ bool zk_sep_stream_preferred(const zk_plan* p, int dtype, int64_t n_patches) {
   return p->sep && p->sep->stream[dtype == ZK_F32 ? 0 : 1].preferred && n_patches >= 98304;
 }
 
-int zk_launch_sep_stream(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {
+#endif
+
+int ZK_GROUP_FN(zk_launch_sep_stream)(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,
+                                      hipStream_t s) {
+#if ZK_NMAX_GROUP == 0
+  if (p->sep->kernel_nmax > 12) return zk_launch_sep_stream_g1(p, in, dtype, n_patches, out, s);
+#endif
   if (((uintptr_t)in & (dtype == ZK_F32 ? 3 : 7)) || ((uintptr_t)out & 15))  // element-aligned DMA, 16-B stores
     return zk_launch_generic_patches(p, in, dtype, n_patches, out, s);
   if (dtype == ZK_F64) return launch_t<double>(p, in, n_patches, out, s);

@@ -14,6 +14,7 @@ import numpy as np
 
 ZK_F32, ZK_F64 = 0, 1
 PATH_AUTO, PATH_GENERIC, PATH_FOLDED, PATH_SEPARABLE, PATH_STREAM = 0, 1, 2, 3, 4
+OP_POINTS, OP_MAPS = 1, 2
 PATH_NAMES = {PATH_GENERIC: "generic", PATH_FOLDED: "folded", PATH_SEPARABLE: "separable", PATH_STREAM: "stream"}
 
 # MTFLEARN_AMD_LIB: alternative build of the same ABI (e.g. a timing-only ablation variant)
@@ -29,6 +30,7 @@ SYMBOLS = {
                                c_int, POINTER(c_void_p)]),
     "zk_plan_destroy": (None, [c_void_p]),
     "zk_plan_has_path": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "zk_plan_supports": (c_int, [c_void_p, c_int, c_int]),
     "zk_plan_disk_pixels": (c_int, [c_void_p]),
     "zk_plan_set_path": (c_int, [c_void_p, c_int]),
     "zk_transform_patches": (c_int, [c_void_p, c_void_p, c_int, c_int64, POINTER(c_double)]),
@@ -150,6 +152,10 @@ class Plan:
     def has_path(self, mode, dtype_code_, path):
         """True if kernel family ``path`` exists for mode (0 batch, 1 frame) and element type."""
         return bool(self._lib.zk_plan_has_path(self._h, mode, dtype_code_, path))
+
+    def supports(self, op, dtype_code_):
+        """True if the plan has the key-point (OP_POINTS) / fused-maps (OP_MAPS) kernel for the element type."""
+        return bool(self._lib.zk_plan_supports(self._h, op, dtype_code_))
 
     def best_path(self, mode, dtype_code_):
         for path in (PATH_SEPARABLE, PATH_STREAM, PATH_FOLDED, PATH_GENERIC):

@@ -162,8 +162,7 @@ class ZPs(BaseEstimator, TransformerMixin):
             return zmoments(np.empty((0, len(self.n))), self.n, self.m, patch_size=self.size)
         operand = self._device_operand(image)
         plan = self._device_plan()
-        if plan.has_path(1, _native.dtype_code(operand.dtype), _native.PATH_SEPARABLE) or \
-                plan.has_path(0, _native.dtype_code(operand.dtype), _native.PATH_SEPARABLE):
+        if plan.supports(_native.OP_POINTS, _native.dtype_code(operand.dtype)):
             data = plan.transform_points(operand, pts)
         else:  # shapes without the separable tables: gather on the host, batch kernel on the device
             s1 = self.size // 2
@@ -236,7 +235,7 @@ class ZPs(BaseEstimator, TransformerMixin):
         operand = self._device_operand(image)
         plan = self._device_plan()
         code = _native.dtype_code(operand.dtype)
-        fused = (plan.has_path(1, code, _native.PATH_SEPARABLE) and p in (2, None) and len(folds) <= 8
+        fused = (plan.supports(_native.OP_MAPS, code) and p in (2, None) and len(folds) <= 8
                  and all(int(f) == f and f > 0 for f in folds))
         out = {}
         if fused:

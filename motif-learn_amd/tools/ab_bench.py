@@ -92,7 +92,7 @@ def main():
             run(lib, h)
             n, ms = c_int64(), c_double()
             lib.zk_plan_profile_read(h, byref(n), byref(ms))
-            ts.append(ms.value / max(n.value, 1))
+            ts.append(ms.value)  # one call per read: the sum over its launches (class-pass kernels: several)
     for name, lib, h, ts in plans:
         med = statistics.median(ts)
         print(f"{name:36s} median {med:7.3f} ms  min {min(ts):7.3f}  max {max(ts):7.3f}   "

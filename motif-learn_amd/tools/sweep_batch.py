@@ -61,7 +61,7 @@ def main():
                 plan.transform_patches_dev(src.data_ptr(), code, n, outs[p].data_ptr(), 0)
                 torch.cuda.synchronize()
                 ln, ms = plan.profile_read()
-                times[p].append(ms / ln)
+                times[p].append(ms)  # one call per read: the sum over its launches (n_max > 16: 4 passes + 1)
         plan.profile(False)
         plan.set_path(_native.PATH_AUTO)
         bytes_alg = n * (K * K * esz + 8 * n_poly)
