@@ -24,10 +24,17 @@
 #define ZK_GROUP_FN(name) name##_g2
 #endif
 
+// n_max 11-12 needs 264 registers; capped at 256 (8 spilled outside the pixel loop) two waves share a SIMD:
+// 2.65 -> 1.91 ms per 2048^2 at (32, 12), 7.32 -> 5.43 ms at (64, 12)
+#ifndef ZK_FRAME_W12
+#define ZK_FRAME_W12 2
+#endif
+#define ZK_FRAME_WAVES(NMAX) ((NMAX) == 12 ? ZK_FRAME_W12 : 1)
+
 namespace {
 
 template <int NMAX, typename T, int MASK>
-__global__ __launch_bounds__(256) void zk_frame_sep_kernel(
+__global__ __launch_bounds__(256, ZK_FRAME_WAVES(NMAX)) void zk_frame_sep_kernel(
     const T* __restrict__ img, double* __restrict__ out, const zk_sep_row* __restrict__ rows,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
     int n_tab_rows, int K, int H, int W, int row0, int n_rows, int tile_pitch) {
@@ -119,8 +126,12 @@ int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int
     case 12: return launch_one<12, T>(p, in, H, W, row0, n_rows, out, s);
 #endif
 #if ZK_NMAX_GROUP == 1
-    case 14: return launch_one<14, T>(p, in, H, W, row0, n_rows, out, s);
-    case 16: return launch_one<16, T>(p, in, H, W, row0, n_rows, out, s);
+    // 330-400 registers in one pass (one wave per SIMD) against 4 class passes at two waves per SIMD that redo
+    // the folds and the tile staging: the passes win while the T product and the row ends weigh enough, i.e. for
+    // small windows (1024^2 frame, ms: (32,14) 1.07 -> 0.78, (48,14) 1.69 -> 1.51, (72,14) 2.92 -> 3.51;
+    // (32,16) 1.54 -> 0.93, (48,16) 2.12 -> 1.68, (72,16) 3.45 -> 3.74)
+    case 14: return p->size <= 56 ? launch_passes<14, T>(p, in, H, W, row0, n_rows, out, s) : launch_one<14, T>(p, in, H, W, row0, n_rows, out, s);
+    case 16: return p->size <= 56 ? launch_passes<16, T>(p, in, H, W, row0, n_rows, out, s) : launch_one<16, T>(p, in, H, W, row0, n_rows, out, s);
 #endif
 #if ZK_NMAX_GROUP == 2
     case 20: return launch_passes<20, T>(p, in, H, W, row0, n_rows, out, s);

@@ -68,11 +68,15 @@ namespace {
 #define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+#ifndef ZK_BATCH_2W
+#define ZK_BATCH_2W 10  // largest kernel n_max compiled for two waves per SIMD
+#endif
+
 // MASK: the parity classes this launch computes -- all of them (15), or one class per launch for
 // n_max > 16 (zk_sep.h); a class pass writes its moments as planes of a scratch matrix [column][patch]
 // (coalesced over the lanes), which zk_transpose_kernel turns into the (N, n_poly) rows afterwards.
 template <int NMAX, int RUN, typename TIN, bool WIDE, int MASK = 15>
-__global__ __launch_bounds__(256, ((NMAX <= 10 || MASK != 15) ? 2 : 1)) void zk_patch_sep_kernel(
+__global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1)) void zk_patch_sep_kernel(
     const TIN* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
     int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp, const int32_t* __restrict__ row_starts,
