@@ -34,8 +34,11 @@
 
 #define ZK_MAX_FOLDS 8
 // waves per SIMD the register allocator is asked to fit (launch bound)
+#ifndef ZK_MAPS_2W
+#define ZK_MAPS_2W 12  // (12 at two waves: 4.23 -> 3.86 ms per 2048^2 with all outputs)
+#endif
 #ifndef ZK_MAPS_WAVES
-#define ZK_MAPS_WAVES(NMAX) ((NMAX) <= 8 ? 3 : (NMAX) <= 10 ? 2 : 1)
+#define ZK_MAPS_WAVES(NMAX) ((NMAX) <= 8 ? 3 : (NMAX) <= ZK_MAPS_2W ? 2 : 1)
 #endif
 
 struct zk_maps_params {

@@ -27,8 +27,13 @@
 
 namespace {
 
+// (two waves per SIMD at n_max 12: sorted points 2.14 -> 1.50 ms per 2^20, random points 3.98 -> 5.77: kept at one)
+#ifndef ZK_POINTS_W12
+#define ZK_POINTS_W12 1
+#endif
+
 template <int NMAX, typename T>
-__global__ __launch_bounds__(256) void zk_points_sep_kernel(
+__global__ __launch_bounds__(256, (NMAX == 12 ? ZK_POINTS_W12 : 1)) void zk_points_sep_kernel(
     const T* __restrict__ img, const int32_t* __restrict__ pts, double* __restrict__ out,
     const zk_sep_row* __restrict__ rows, const double* __restrict__ xq, const double* __restrict__ tmat,
     const int32_t* __restrict__ colmap, int n_tab_rows, int K, int H, int W, long long n_points, int n_poly) {

@@ -9,7 +9,8 @@ from mtflearn_amd import ZPs, _native
 from mtflearn_amd.synthetic import honeycomb_frame
 from ctypes import c_void_p
 
-z = ZPs(8, 32); plan = z._device_plan()
+n_max = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+z = ZPs(n_max, 32); plan = z._device_plan()
 img = torch.from_numpy(honeycomb_frame(2048, seed=1)).cuda()
 rng = np.random.default_rng(0)
 for n_pts, kind in [(1 << 20, "random"), (1 << 20, "sorted"), (100000, "random")]:
@@ -17,7 +18,7 @@ for n_pts, kind in [(1 << 20, "random"), (1 << 20, "sorted"), (100000, "random")
     if kind == "sorted":
         pts = pts[np.lexsort((pts[:, 0], pts[:, 1]))]
     d_pts = torch.from_numpy(pts).cuda()
-    out = torch.empty((n_pts, 45), dtype=torch.float64, device="cuda")
+    out = torch.empty((n_pts, len(z.n)), dtype=torch.float64, device="cuda")
     lib = plan._lib
     run = lambda: _native.check(lib.zk_transform_points_dev(plan._h, c_void_p(img.data_ptr()), 0, 2048, 2048,
                                                             c_void_p(d_pts.data_ptr()), n_pts, c_void_p(out.data_ptr()), None), "pts")
