@@ -75,8 +75,8 @@ void zk_plan_destroy(zk_plan* plan);
 
 /* Introspection: 1 if `path` (ZK_PATH_*) is available for `mode` (0 patches, 1 frame) and `dtype`. */
 int zk_plan_has_path(const zk_plan* plan, int mode, int dtype, int path);
-/* 1 if the plan has the kernel behind zk_transform_points (ZK_OP_POINTS) / zk_frame_maps (ZK_OP_MAPS) for
- * `dtype`: both need the row-separable tables and all moments of a unit in one pass, i.e. the full Zernike
+/* 1 if the plan has the single-kernel form of zk_transform_points (ZK_OP_POINTS) / the kernel behind
+ * zk_frame_maps (ZK_OP_MAPS) for `dtype`: both need the row-separable tables and all moments of a unit in one pass, i.e. the full Zernike
  * set with n_max <= 16.  (No reference counterpart: the reference composes these from ZPs.transform.) */
 #define ZK_OP_POINTS 1
 #define ZK_OP_MAPS   2
@@ -122,8 +122,9 @@ int zk_transform_frame_dev(zk_plan* plan, const void* image_dev, int dtype, int6
  *            image[y - size/2 : y - size/2 + size, x - size/2 : x - size/2 + size]  (pixels outside the
  *            frame read as zero; the reference's KeyPoints drops such points beforehand)
  *   out    : (n_points, n_poly) float64
- * Needs the row-separable tables (any size; n_max <= 10); otherwise fails and the caller gathers the
- * patches and uses zk_transform_patches.
+ * Plans with the key-point kernel (zk_plan_supports(plan, ZK_OP_POINTS, dtype): full Zernike set, n_max <= 16)
+ * read the windows straight from the frame; the others cut them on the device into a plan-owned batch
+ * (<= 1 GiB at a time) and run the batch path on it.
  */
 int zk_transform_points(zk_plan* plan, const void* image_host, int dtype, int64_t height, int64_t width,
                         const int32_t* points_host, int64_t n_points, double* out_host);

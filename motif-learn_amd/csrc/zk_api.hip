@@ -125,6 +125,7 @@ extern "C" void zk_plan_destroy(zk_plan* p) {
   if (p->d_in) (void)hipFree(p->d_in);
   if (p->d_out) (void)hipFree(p->d_out);
   if (p->d_scratch) (void)hipFree(p->d_scratch);
+  if (p->d_gather) (void)hipFree(p->d_gather);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
@@ -381,7 +382,22 @@ extern "C" int zk_transform_points_dev(zk_plan* p, const void* image, int dtype,
   if (n_points == 0) return 0;
   if (!image || !points || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
   ZK_HIP(hipSetDevice(p->device));
-  return zk_launch_sep_points(p, image, dtype, H, W, points, n_points, out, (hipStream_t)hip_stream);
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (zk_sep_points_available(p, dtype)) return zk_launch_sep_points(p, image, dtype, H, W, points, n_points, out, s);
+  // Plans without the key-point kernel (n_max > 16, sets or bases off the separable path): cut the windows
+  // on the device into a plan-owned batch, chunk by chunk, and run the batch path on it -- what the
+  // reference does on the host (features/_keypoint.py:60-78 + _zps.py:146-157).
+  const size_t patch_bytes = (size_t)p->size * p->size * elem_size(dtype);
+  int64_t chunk = (int64_t)((size_t)1 << 30) / (int64_t)patch_bytes;  // <= 1 GiB of windows at a time
+  if (chunk < 64) chunk = 64;
+  if (chunk > n_points) chunk = n_points;
+  if ((rc = ensure(&p->d_gather, &p->d_gather_bytes, (size_t)chunk * patch_bytes))) return rc;
+  for (int64_t first = 0; first < n_points; first += chunk) {
+    const int64_t n = n_points - first < chunk ? n_points - first : chunk;
+    if ((rc = zk_launch_gather_points(p, image, dtype, H, W, points + 2 * first, n, p->d_gather, s))) return rc;
+    if ((rc = zk_transform_patches_dev(p, p->d_gather, dtype, n, out + first * p->n_poly, hip_stream))) return rc;
+  }
+  return 0;
 }
 
 extern "C" int zk_transform_points(zk_plan* p, const void* image_host, int dtype, int64_t H, int64_t W,

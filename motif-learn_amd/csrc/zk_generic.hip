@@ -70,6 +70,22 @@ __global__ __launch_bounds__(256) void zk_generic_kernel(
   }
 }
 
+// Windows at key points -> (N, K, K) batch: the slice img[y-s1:y+s2, x-s1:x+s2] of the reference
+// (features/_keypoint.py:60-78; s1 = K//2, s2 = K - K//2), zero outside the frame.  One thread per pixel,
+// consecutive lanes along a window row.
+template <typename T>
+__global__ __launch_bounds__(256) void zk_gather_points_kernel(const T* __restrict__ img, const int32_t* __restrict__ pts,
+                                                               T* __restrict__ out, int K, int H, int W,
+                                                               long long n_points) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int kk = K * K;
+  const long long p = t / kk;
+  if (p >= n_points) return;
+  const int q = (int)(t - p * kk), r = q / K, c = q - r * K;
+  const int yy = pts[2 * p + 1] - K / 2 + r, xx = pts[2 * p] - K / 2 + c;
+  out[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[(long long)yy * W + xx] : (T)0;
+}
+
 template <int MODE>
 int launch(zk_plan* p, const void* in, int dtype, long long n_units, int H, int W, int row0,
            double* out, hipStream_t s) {
@@ -92,6 +108,21 @@ int launch(zk_plan* p, const void* in, int dtype, long long n_units, int H, int 
 }
 
 }  // namespace
+
+int zk_launch_gather_points(zk_plan* p, const void* img, int dtype, int64_t H, int64_t W, const int32_t* pts,
+                            int64_t n_points, void* patches, hipStream_t s) {
+  const long long threads = (long long)n_points * p->size * p->size;
+  const long long blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffLL) return zk_fail(ZK_E_BADARG, "too many points for one launch");
+  if (dtype == ZK_F32)
+    hipLaunchKernelGGL(zk_gather_points_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)img, pts,
+                       (float*)patches, p->size, (int)H, (int)W, (long long)n_points);
+  else
+    hipLaunchKernelGGL(zk_gather_points_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, (const double*)img, pts,
+                       (double*)patches, p->size, (int)H, (int)W, (long long)n_points);
+  ZK_HIP(hipGetLastError());
+  return 0;
+}
 
 int zk_launch_generic_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,
                               hipStream_t s) {

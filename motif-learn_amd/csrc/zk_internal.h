@@ -44,6 +44,8 @@ struct zk_plan {
   size_t d_in_bytes = 0;
   double* d_out = nullptr;
   size_t d_out_bytes = 0;
+  void* d_gather = nullptr;      // key points without the key-point kernel: windows cut on the device
+  size_t d_gather_bytes = 0;
   double* d_scratch = nullptr;   // class-pass batch kernels (n_max > 16): [n_poly][chunk] planes
   size_t d_scratch_bytes = 0;
 
@@ -70,6 +72,8 @@ int zk_prof_end(zk_plan* p, hipStream_t s);
 // kernel launchers; each returns 0 or a negative code.
 int zk_launch_generic_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,
                               hipStream_t s);
+int zk_launch_gather_points(zk_plan* p, const void* img, int dtype, int64_t H, int64_t W, const int32_t* pts,
+                            int64_t n_points, void* patches, hipStream_t s);  // zk_generic.hip
 int zk_launch_generic_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,
                             int64_t n_rows, double* out, hipStream_t s);
 

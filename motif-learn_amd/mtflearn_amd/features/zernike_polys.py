@@ -162,14 +162,7 @@ class ZPs(BaseEstimator, TransformerMixin):
             return zmoments(np.empty((0, len(self.n))), self.n, self.m, patch_size=self.size)
         operand = self._device_operand(image)
         plan = self._device_plan()
-        if plan.supports(_native.OP_POINTS, _native.dtype_code(operand.dtype)):
-            data = plan.transform_points(operand, pts)
-        else:  # shapes without the separable tables: gather on the host, batch kernel on the device
-            s1 = self.size // 2
-            padded = np.pad(operand, self.size)
-            batch = np.stack([padded[y + self.size - s1:y + 2 * self.size - s1,
-                                     x + self.size - s1:x + 2 * self.size - s1] for x, y in pts])
-            data = plan.transform_patches(np.ascontiguousarray(batch))
+        data = plan.transform_points(operand, pts)  # (plans without the key-point kernel gather on the device)
         return zmoments(data=data, n=self.n, m=self.m, patch_size=self.size)
 
     def transform_grid(self, image, step=1) -> zmoments:

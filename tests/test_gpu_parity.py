@@ -139,6 +139,13 @@ def test_moments_at_key_points(native, zo):
     padded = np.pad(frame, 32)
     refp = np.array([padded[y + 16:y + 48, x + 16:x + 48] for x, y in [(0, 0), (63, 63), (5, 60)]])
     rel_close(edge, zo.moments_patches(refp, z.polynomials))
+    # plans without the key-point kernel (n_max > 16) cut the windows on the device: same zero padding
+    z18 = _zps(18, 24)
+    assert not z18._device_plan().supports(native.OP_POINTS, native.ZK_F32)
+    edge18 = z18.transform_at(frame, [[0, 0], [63, 63], [5, 60], [30, 31]]).data
+    padded = np.pad(frame, 24)
+    ref18 = np.array([padded[y + 12:y + 36, x + 12:x + 36] for x, y in [(0, 0), (63, 63), (5, 60), (30, 31)]])
+    rel_close(edge18, zo.moments_patches(ref18, z18.polynomials), atol_scale=1e-8)
     assert z.transform_at(frame, np.empty((0, 2))).data.shape == (0, 45)
 
 
