@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-frame side measurement")
     ap.add_argument("--no-maps", action="store_true", help="skip the configs[4] symmetry-map side measurement")
+    ap.add_argument("--no-4096", action="store_true", help="skip the north-star 4096^2 batch side measurement")
     return ap.parse_args()
 
 
@@ -256,7 +257,14 @@ def main():
         row_pairs = int(np.any(z.polynomials[0][:(K + 1) // 2] != 0, axis=1).sum())
         cls = [sum(1 for a in range(args.n_max + 1) for b in range(args.n_max + 1 - a) if (a % 2, b % 2) == pq)
                for pq in ((0, 0), (1, 0), (0, 1), (1, 1))]
-        sep_flops = quad_px * (8 + 4 * (args.n_max + 1)) + 2 * row_pairs * n_poly + 2 * sum(c * c for c in cls)
+        # (T is stored packed: entry (j, (a,b)) exists only for a + b <= n_j)
+        t_terms = 0
+        for pq, m_sel in (((0, 0), lambda m: m >= 0 and m % 2 == 0), ((1, 0), lambda m: m >= 0 and m % 2 == 1),
+                          ((0, 1), lambda m: m < 0 and m % 2 == 1), ((1, 1), lambda m: m < 0 and m % 2 == 0)):
+            degs = [a + b for a in range(args.n_max + 1) for b in range(args.n_max + 1 - a) if (a % 2, b % 2) == pq]
+            zns = [n for n in range(args.n_max + 1) for m in range(-n, n + 1, 2) if m_sel(m)]
+            t_terms += sum(1 for n in zns for d in degs if d <= n)
+        sep_flops = quad_px * (8 + 4 * (args.n_max + 1)) + 2 * row_pairs * n_poly + 2 * t_terms
         dense = {"positions": npx, "bound": "fp64-valu", "fp64_vector_peak_TFLOPs": FP64_VECTOR_PEAK_TF,
                  "kernels": {}}
         for path in (_native.PATH_SEPARABLE, _native.PATH_FOLDED):
@@ -318,6 +326,37 @@ def main():
                 "out_bytes_fused": 41 * 4096 * 4096 * 8, "out_bytes_moments": 66 * 4096 * 4096 * 8}
             del mom
         del big
+
+    # ---- north star's own size: all dense 32-px windows of a 4096^2 frame as one batch (side measurement) --
+    if world == 1 and not args.no_4096 and K == 32:
+        try:
+            del patches, outs                                            # (already gone if the maps section ran)
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        free_b, _tot = torch.cuda.mem_get_info()
+        n4 = (4096 - K + 1) ** 2
+        need = n4 * (K * K * 4 + 8 * n_poly) + 4096 * 4096 * 4
+        if free_b > need * 1.1:
+            f4 = torch.from_numpy(honeycomb_frame(4096, seed=2)).to(dev)
+            p4 = f4.unfold(0, K, 1).unfold(1, K, 1).reshape(-1, K, K).contiguous()
+            o4 = torch.empty((n4, n_poly), dtype=torch.float64, device=dev)
+            patch_moments_device(plan, p4, out=o4)
+            torch.cuda.synchronize()
+            plan.profile(True)
+            for _ in range(5):
+                patch_moments_device(plan, p4, out=o4)
+            torch.cuda.synchronize()
+            ln4, ms4 = plan.profile_read()
+            plan.profile(False)
+            k4 = ms4 / ln4
+            result["north_star_4096"] = {
+                "workload": f"all {n4} dense {K}-px windows of a 4096x4096 frame as one float32 batch ({n4 * K * K * 4 / 1e9:.1f} GB), n_max={args.n_max}",
+                "kernel_ms": k4, "patches_per_s": n4 / (k4 * 1e-3),
+                "hbm_GBps_algorithmic": n4 * (K * K * 4 + 8 * n_poly) / (k4 * 1e-3) / 1e9,
+                "hbm_frac": n4 * (K * K * 4 + 8 * n_poly) / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del p4, o4, f4
+            torch.cuda.empty_cache()
 
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(z, frame, K)
