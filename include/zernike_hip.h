@@ -75,9 +75,9 @@ void zk_plan_destroy(zk_plan* plan);
 
 /* Introspection: 1 if `path` (ZK_PATH_*) is available for `mode` (0 patches, 1 frame) and `dtype`. */
 int zk_plan_has_path(const zk_plan* plan, int mode, int dtype, int path);
-/* 1 if the plan has the single-kernel form of zk_transform_points (ZK_OP_POINTS) / the kernel behind
- * zk_frame_maps (ZK_OP_MAPS) for `dtype`: both need the row-separable tables and all moments of a unit in one pass, i.e. the full Zernike
- * set with n_max <= 16.  (No reference counterpart: the reference composes these from ZPs.transform.) */
+/* 1 if the plan has the single-kernel form of zk_transform_points (ZK_OP_POINTS: full Zernike set, n_max <= 16) /
+ * the kernels behind zk_frame_maps (ZK_OP_MAPS: full Zernike set, n_max <= 20; fused in one kernel up to 16)
+ * for `dtype`.  (No reference counterpart: the reference composes these from ZPs.transform.) */
 #define ZK_OP_POINTS 1
 #define ZK_OP_MAPS   2
 int zk_plan_supports(const zk_plan* plan, int op, int dtype);

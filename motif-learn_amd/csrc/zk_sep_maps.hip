@@ -57,54 +57,14 @@ __device__ __forceinline__ void zk_for_each_int(F&& f, std::integer_sequence<int
   (f(std::integral_constant<int, Is>{}), ...);
 }
 
-template <int NMAX, typename T>
-__global__ __launch_bounds__(256, ZK_MAPS_WAVES(NMAX)) void zk_frame_maps_kernel(
-    const T* __restrict__ img, const zk_sep_row* __restrict__ rows, const double* __restrict__ xq,
-    const double* __restrict__ tmat, const double* __restrict__ trig, double* __restrict__ rot_out,
-    double* __restrict__ abs_out, double* __restrict__ mirror_out, zk_maps_params prm, int n_tab_rows, int K, int H,
-    int W, int row0, int n_rows, int tile_pitch) {
+// The symmetry-map tail shared by the fused kernel (moments from the T product in registers) and the
+// planes kernel (moments from a (N_poly, rows, W) matrix in memory): `get(n, |m|, A, B)` delivers the
+// complex moment A + iB = Z_{n,+m} + i Z_{n,-m} of this lane's pixel.  `pix` / `plane` address the outputs.
+template <int NMAX, typename GET>
+__device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& prm, const double* __restrict__ trig,
+                                             bool live, long long plane, long long pix, double* __restrict__ rot_out,
+                                             double* __restrict__ abs_out, double* __restrict__ mirror_out) {
   using Z = zk_set<NMAX>;
-  extern __shared__ __attribute__((aligned(16))) double tile[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int ea = K - 1 - (K - 1) / 2;
-  const int i0 = row0 + blockIdx.y * 4;
-  const int k0 = blockIdx.x * 64;
-  const int tile_elems = (K + 3) * tile_pitch;
-
-  for (int e = tid; e < tile_elems; e += 256) {
-    const int tr = e / tile_pitch;
-    const int tc = e - tr * tile_pitch;
-    const int ii = i0 - ea + tr;
-    const int kk = k0 - ea + tc;
-    double v = 0.0;
-    if (ii >= 0 && ii < H && kk >= 0 && kk < W) v = (double)img[(long long)ii * W + kk];
-    tile[e] = v;
-  }
-  __syncthreads();
-
-  zk_sep_acc<NMAX> acc;
-  acc.clear_all();
-  const double* __restrict__ mine = tile + wave * tile_pitch + lane;
-  const ZK_CONST int32_t* rtab = zk_const((const int32_t*)rows);
-  const ZK_CONST double* px = zk_const(xq);
-  const int Q = (K + 1) / 2;
-  for (int ri = 0; ri < n_tab_rows; ++ri) {
-    const int r = rtab[2 * ri], cmin = rtab[2 * ri + 1];
-    const double* __restrict__ top = mine + r * tile_pitch;
-    const double* __restrict__ bot = mine + (K - 1 - r) * tile_pitch;
-    zk_sep_row_pair<NMAX>(acc, top, bot, cmin, Q, K, px);
-    acc.row_end(px + r * ZK_SEP_ROW);
-  }
-
-  // ---- fused tail ---------------------------------------------------------------------------------
-  const int oi = i0 + wave;
-  const int ok = k0 + lane;
-  const bool live = oi < row0 + n_rows && ok < W;
-  const long long plane = (long long)n_rows * W;
-  const long long pix = (long long)(oi - row0) * W + ok;
-
   // per-|m| sums over n of the complex moments A + iB:  E = A^2 + B^2,  C = A^2 - B^2,  S = 2AB
   double Em[NMAX + 1], Cm[NMAX + 1], Sm[NMAX + 1];
 #pragma unroll
@@ -123,13 +83,11 @@ __global__ __launch_bounds__(256, ZK_MAPS_WAVES(NMAX)) void zk_frame_maps_kernel
 
   // +m and -m of one (n, |m|) are produced back to back (they live in partner parity classes of the T
   // product) and folded into the running sums at once, so no moment outlives its own combine().
-  const ZK_CONST double* tb = zk_const(tmat);
   zk_for_each_int(
       [&](auto k) {
         constexpr int n = Z::complex_n(decltype(k)::value), am = Z::complex_m(decltype(k)::value);
-        const double A = acc.template moment<Z::slot_of(n, am)>(tb);
-        double B = 0.0;
-        if constexpr (am > 0) B = acc.template moment<Z::slot_of(n, -am)>(tb);
+        double A, B = 0.0;
+        get(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
         combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
       },
       std::make_integer_sequence<int, Z::NC>{});
@@ -202,6 +160,92 @@ __global__ __launch_bounds__(256, ZK_MAPS_WAVES(NMAX)) void zk_frame_maps_kernel
 }
 
 template <int NMAX, typename T>
+__global__ __launch_bounds__(256, ZK_MAPS_WAVES(NMAX)) void zk_frame_maps_kernel(
+    const T* __restrict__ img, const zk_sep_row* __restrict__ rows, const double* __restrict__ xq,
+    const double* __restrict__ tmat, const double* __restrict__ trig, double* __restrict__ rot_out,
+    double* __restrict__ abs_out, double* __restrict__ mirror_out, zk_maps_params prm, int n_tab_rows, int K, int H,
+    int W, int row0, int n_rows, int tile_pitch) {
+  using Z = zk_set<NMAX>;
+  extern __shared__ __attribute__((aligned(16))) double tile[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int ea = K - 1 - (K - 1) / 2;
+  const int i0 = row0 + blockIdx.y * 4;
+  const int k0 = blockIdx.x * 64;
+  const int tile_elems = (K + 3) * tile_pitch;
+
+  for (int e = tid; e < tile_elems; e += 256) {
+    const int tr = e / tile_pitch;
+    const int tc = e - tr * tile_pitch;
+    const int ii = i0 - ea + tr;
+    const int kk = k0 - ea + tc;
+    double v = 0.0;
+    if (ii >= 0 && ii < H && kk >= 0 && kk < W) v = (double)img[(long long)ii * W + kk];
+    tile[e] = v;
+  }
+  __syncthreads();
+
+  zk_sep_acc<NMAX> acc;
+  acc.clear_all();
+  const double* __restrict__ mine = tile + wave * tile_pitch + lane;
+  const ZK_CONST int32_t* rtab = zk_const((const int32_t*)rows);
+  const ZK_CONST double* px = zk_const(xq);
+  const int Q = (K + 1) / 2;
+  for (int ri = 0; ri < n_tab_rows; ++ri) {
+    const int r = rtab[2 * ri], cmin = rtab[2 * ri + 1];
+    const double* __restrict__ top = mine + r * tile_pitch;
+    const double* __restrict__ bot = mine + (K - 1 - r) * tile_pitch;
+    zk_sep_row_pair<NMAX>(acc, top, bot, cmin, Q, K, px);
+    acc.row_end(px + r * ZK_SEP_ROW);
+  }
+
+  // ---- fused tail ---------------------------------------------------------------------------------
+  const int oi = i0 + wave;
+  const int ok = k0 + lane;
+  const bool live = oi < row0 + n_rows && ok < W;
+  const long long plane = (long long)n_rows * W;
+  const long long pix = (long long)(oi - row0) * W + ok;
+
+  const ZK_CONST double* tb = zk_const(tmat);
+  zk_maps_tail<NMAX>(
+      [&](auto nn, auto amm, double& A, double& B) {
+        // +m and -m of one (n, |m|) are produced back to back (they live in partner parity classes of the
+        // T product) and folded into the running sums at once, so no moment outlives its own combine()
+        constexpr int n = decltype(nn)::value, am = decltype(amm)::value;
+        A = acc.template moment<Z::slot_of(n, am)>(tb);
+        if constexpr (am > 0) B = acc.template moment<Z::slot_of(n, -am)>(tb);
+      },
+      prm, trig, live, plane, pix, rot_out, abs_out, mirror_out);
+}
+
+// Planes form (plans whose moments come out of several kernel launches, n_max > 16): one lane per pixel,
+// moments read from the (N_poly, mom_rows, W) matrix the dense kernels just wrote (plane j of (n, m) is
+// the reference index j = (n (n + 2) + m) / 2), outputs written at row offset `out_row0` of (.., out_rows, W).
+template <int NMAX>
+__global__ __launch_bounds__(256) void zk_maps_planes_kernel(const double* __restrict__ mom, const double* __restrict__ trig,
+                                                             double* __restrict__ rot_out, double* __restrict__ abs_out,
+                                                             double* __restrict__ mirror_out, zk_maps_params prm,
+                                                             int mom_rows, int W, int out_row0, int out_rows) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long mplane = (long long)mom_rows * W;
+  const bool live = t < mplane;
+  const long long mp = live ? t : 0;
+  const long long pix = mp + (long long)out_row0 * W;
+  zk_maps_tail<NMAX>(
+      [&](auto nn, auto amm, double& A, double& B) {
+        constexpr int n = decltype(nn)::value, am = decltype(amm)::value;
+        if (n <= prm.plan_nmax) {  // wave-uniform: planes above the plan's n_max do not exist
+          A = mom[(long long)((n * (n + 2) + am) / 2) * mplane + mp];
+          if constexpr (am > 0) B = mom[(long long)((n * (n + 2) - am) / 2) * mplane + mp];
+        } else {
+          A = 0.0;
+        }
+      },
+      prm, trig, live, (long long)out_rows * W, pix, rot_out, abs_out, mirror_out);
+}
+
+template <int NMAX, typename T>
 int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
                hipStream_t s) {
@@ -249,20 +293,53 @@ int ZK_GROUP_FN(zk_maps_dispatch)(zk_plan* p, const void* in, int dtype, int64_t
   return launch_t<double>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
 }
 
+#if ZK_NMAX_GROUP == 2
+// n_max 17-20: the moments of a row band come from the class-pass dense kernel into the plan's scratch
+// matrix (<= 1 GiB at a time), the planes kernel turns them into the maps of those rows.
+int zk_maps_planes_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                      const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
+                      hipStream_t s) {
+  int64_t band = (int64_t)((size_t)1 << 30) / ((int64_t)p->n_poly * W * (int64_t)sizeof(double));
+  band = band < 4 ? 4 : (band > n_rows ? n_rows : band);
+  const size_t need = (size_t)p->n_poly * band * W * sizeof(double);
+  if (p->d_scratch_bytes < need) {
+    if (p->d_scratch) ZK_HIP(hipFree(p->d_scratch));
+    p->d_scratch = nullptr;
+    p->d_scratch_bytes = 0;
+    ZK_HIP(hipMalloc((void**)&p->d_scratch, need));
+    p->d_scratch_bytes = need;
+  }
+  for (int64_t b0 = 0; b0 < n_rows; b0 += band) {
+    const int64_t nb = n_rows - b0 < band ? n_rows - b0 : band;
+    int rc = zk_launch_sep_frame(p, in, dtype, H, W, row0 + b0, nb, p->d_scratch, s);
+    if (rc) return rc;
+    if ((rc = zk_prof_begin(p, s))) return rc;
+    hipLaunchKernelGGL(zk_maps_planes_kernel<20>, dim3((unsigned)((nb * W + 255) / 256)), dim3(256), 0, s, p->d_scratch,
+                       d_trig, rot, ab, mirror, prm, (int)nb, (int)W, (int)b0, (int)n_rows);
+    ZK_HIP(hipGetLastError());
+    if ((rc = zk_prof_end(p, s))) return rc;
+  }
+  return 0;
+}
+#endif
+
 #if ZK_NMAX_GROUP == 0
+int zk_maps_planes_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                      const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
+                      hipStream_t s);
 int zk_maps_dispatch_g1(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                         const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
                         hipStream_t s);
 
 bool zk_sep_maps_available(const zk_plan* p, int dtype) {
-  return zk_sep_frame_available(p, dtype) && p->sep->kernel_nmax <= 16;  // needs all classes in one pass
+  return zk_sep_frame_available(p, dtype);  // n_max <= 16: fused in one kernel; 17-20: dense passes + planes kernel
 }
 
 int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                        const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
                        const double* theta, int n_theta, double* rot, double* ab, double* mirror, hipStream_t s) {
   if (!zk_sep_maps_available(p, dtype))
-    return zk_fail(ZK_E_BADARG, "plan has no fused maps kernel (needs the separable tables: n_max <= 16)");
+    return zk_fail(ZK_E_BADARG, "plan has no symmetry-map kernels (needs the separable tables: n_max <= 20)");
   if (n_folds < 0 || n_folds > ZK_MAX_FOLDS) return zk_fail(ZK_E_BADARG, "at most 8 folds per call");
   if (p_norm != 0 && p_norm != 2) return zk_fail(ZK_E_BADARG, "p must be 2 or 0 (None)");
   if (rot && (!folds || n_folds == 0)) return zk_fail(ZK_E_BADARG, "rot output requested without folds");
@@ -319,6 +396,7 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
   // stream-ordered upload from a pageable stack-lifetime buffer: synchronise before it goes away
   ZK_HIP(hipMemcpyAsync(t->d_trig, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
   ZK_HIP(hipStreamSynchronize(s));
+  if (knm > 16) return zk_maps_planes_g2(p, in, dtype, H, W, row0, n_rows, prm, t->d_trig, rot, ab, mirror, s);
   if (knm > 12) return zk_maps_dispatch_g1(p, in, dtype, H, W, row0, n_rows, prm, t->d_trig, rot, ab, mirror, s);
   return zk_maps_dispatch(p, in, dtype, H, W, row0, n_rows, prm, t->d_trig, rot, ab, mirror, s);
 }

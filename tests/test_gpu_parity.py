@@ -187,7 +187,8 @@ def test_fused_symmetry_maps(native, golden, zo):
     for n_max, size, shape, dtype in [(8, 32, (70, 90), np.float32), (10, 32, (40, 130), np.float64),
                                       (5, 16, (33, 65), np.float32), (7, 33, (40, 50), np.float32),
                                       (12, 40, (50, 70), np.float32), (14, 32, (40, 60), np.float32),
-                                      (16, 36, (44, 48), np.float64)]:
+                                      (16, 36, (44, 48), np.float64),
+                                      (18, 40, (45, 50), np.float32), (20, 44, (50, 47), np.float64)]:
         zz = _zps(n_max, size)
         frame = (rng.random(shape) + 0.1).astype(dtype)
         zm = zz.transform(frame)
@@ -213,6 +214,22 @@ def test_fused_symmetry_maps(native, golden, zo):
                 assert "mirror_map" not in got
     with pytest.raises(ValueError, match="m=0 must be included"):
         z.symmetry_maps(img, m_unselect=(1,))
+
+
+def test_symmetry_maps_row_bands_above_n_max_16(native):
+    """n_max 17-20: the maps come from dense class passes into a scratch matrix (<= 1 GiB, i.e. row bands on a
+    wide frame) + the planes kernel.  A 4096-wide frame needs several bands; a 512-column crop needs one: the
+    maps must agree wherever the windows see the same pixels."""
+    z = _zps(17, 20)
+    assert z._device_plan().supports(native.OP_MAPS, native.ZK_F32)
+    rng = np.random.default_rng(21)
+    frame = (rng.random((400, 4096)) + 0.2).astype(np.float32)
+    wide = z.symmetry_maps(frame)
+    crop = z.symmetry_maps(np.ascontiguousarray(frame[:, 1000:1512]))
+    for key in ("rot_maps", "abs", "mirror_map"):
+        a, b = wide[key][..., 1020:1492], crop[key][..., 20:492]
+        assert a.shape == b.shape
+        rel_close(a, b, rtol=1e-10, atol_scale=1e-12)
 
 
 # ------------------------------------------------------------------ oracle on seeded inputs, edge cases
