@@ -47,7 +47,8 @@ extern "C" {
 #define ZK_PATH_GENERIC   1  /* any size / n_max / dtype: unfolded direct summation, ~1e-16 of the definition */
 #define ZK_PATH_FOLDED    2  /* frame only: mirror-folded direct summation (4x fewer FMAs), ~1e-15            */
 #define ZK_PATH_SEPARABLE 3  /* mirror-folded row-separable sums (Legendre products), ~1e-13; fastest.  Full
-                                Zernike sets up to n_max 20 (17-20: one pass per mirror-parity class, ~1e-9) */
+                                Zernike sets up to n_max 24 (17-24: one pass per mirror-parity class; ~1e-9 at 20, ~3e-8 at 24,
+                                which is the rounding of the reference's own float64 basis there) */
 #define ZK_PATH_STREAM    4  /* patches only: row-separable sums over the contiguous pixel stream of a patch,
                                 whole 128-B lines whatever the patch size; AUTO prefers it where the row-pair
                                 kernel of ZK_PATH_SEPARABLE would issue half-line requests */
@@ -76,7 +77,7 @@ void zk_plan_destroy(zk_plan* plan);
 /* Introspection: 1 if `path` (ZK_PATH_*) is available for `mode` (0 patches, 1 frame) and `dtype`. */
 int zk_plan_has_path(const zk_plan* plan, int mode, int dtype, int path);
 /* 1 if the plan has the single-kernel form of zk_transform_points (ZK_OP_POINTS: full Zernike set, n_max <= 16) /
- * the kernels behind zk_frame_maps (ZK_OP_MAPS: full Zernike set, n_max <= 20; fused in one kernel up to 16)
+ * the kernels behind zk_frame_maps (ZK_OP_MAPS: full Zernike set, n_max <= 24; fused in one kernel up to 16)
  * for `dtype`.  (No reference counterpart: the reference composes these from ZPs.transform.) */
 #define ZK_OP_POINTS 1
 #define ZK_OP_MAPS   2

@@ -123,7 +123,7 @@ struct zk_sep_meta {
 };
 
 #ifndef ZK_SEP_ROW
-#define ZK_SEP_ROW 24  // doubles per row of the P-value tables (degrees 0..20 used; rows start on 64-B lines)
+#define ZK_SEP_ROW 32  // doubles per row of the P-value tables (degrees 0..24 used)
 #endif
 
 struct zk_sep_row {     // one quadrant row pair (r, K-1-r) with at least one disk pixel

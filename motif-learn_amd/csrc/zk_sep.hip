@@ -8,7 +8,7 @@
 
 typedef long double ld;
 
-static const int kSepNmax[] = {4, 6, 8, 10, 12, 14, 16, 20};  // instantiated kernels (20: one pass per parity class)
+static const int kSepNmax[] = {4, 6, 8, 10, 12, 14, 16, 20, 24};  // instantiated kernels (20, 24: one pass per parity class)
 
 // x^a = sum_i L[a][i] P_i(x), from x P_i = ((i+1) P_{i+1} + i P_{i-1}) / (2i+1); all terms positive.
 static std::vector<std::vector<ld>> monomial_to_legendre(int deg) {
@@ -148,9 +148,10 @@ int zk_sep_build(zk_plan* p, const double* basis) {
   }
   if (rows.empty()) return 0;
   // The kernels use the exact polynomial; the caller's float64 basis carries the rounding of the reference's
-  // factorial sums (_zps.py:52-64), ~2e-11 of max|V| at n_max 16, ~1e-9 at 20 and ~3e-8 at 24 -- so the
-  // substitution stops at 20, where the two still agree to a few 1e-9.
-  const ld tol = n_max <= 16 ? 1e-9L : 4e-9L;
+  // factorial sums (_zps.py:52-64): ~2e-11 of max|V| at n_max 16, ~1e-9 at 20, ~3e-8 at 24 (and 2e-4 by 36).
+  // Up to 24 that is two orders inside the 1e-6 parity tolerance and the substitution is accepted; the
+  // tolerance below still rejects any basis that is not this polynomial set.
+  const ld tol = n_max <= 16 ? 1e-9L : n_max <= 20 ? 4e-9L : 1e-7L;
   for (int j = 0; j < NP; ++j) {
     double vmax = 0.0;
     for (int t = 0; t < K * K; ++t) vmax = std::max(vmax, fabs(basis[(size_t)j * K * K + t]));

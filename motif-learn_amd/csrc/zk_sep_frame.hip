@@ -12,7 +12,7 @@
 
 // Build groups: the kernel instances are spread over several translation units (Makefile) so that they
 // compile in parallel: group 0 = n_max kernels 4..12 (and every non-template entry point), 1 = 14 / 16,
-// 2 = 20 (class-pass kernels).  Group 0's launcher forwards to the others.
+// 2 = 20 / 24 (class-pass kernels).  Group 0's launcher forwards to the others.
 #ifndef ZK_NMAX_GROUP
 #define ZK_NMAX_GROUP 0
 #endif
@@ -135,6 +135,7 @@ int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int
 #endif
 #if ZK_NMAX_GROUP == 2
     case 20: return launch_passes<20, T>(p, in, H, W, row0, n_rows, out, s);
+    case 24: return launch_passes<24, T>(p, in, H, W, row0, n_rows, out, s);
 #endif
   }
   return zk_fail(ZK_E_BADARG, "no separable frame kernel for this n_max");

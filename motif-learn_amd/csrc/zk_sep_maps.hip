@@ -20,7 +20,7 @@
 
 // Build groups: the kernel instances are spread over several translation units (Makefile) so that they
 // compile in parallel: group 0 = n_max kernels 4..12 (and every non-template entry point), 1 = 14 / 16,
-// 2 = 20 (class-pass kernels).  Group 0's launcher forwards to the others.
+// 2 = 20 / 24 (class-pass kernels).  Group 0's launcher forwards to the others.
 #ifndef ZK_NMAX_GROUP
 #define ZK_NMAX_GROUP 0
 #endif
@@ -314,8 +314,13 @@ int zk_maps_planes_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t 
     int rc = zk_launch_sep_frame(p, in, dtype, H, W, row0 + b0, nb, p->d_scratch, s);
     if (rc) return rc;
     if ((rc = zk_prof_begin(p, s))) return rc;
-    hipLaunchKernelGGL(zk_maps_planes_kernel<20>, dim3((unsigned)((nb * W + 255) / 256)), dim3(256), 0, s, p->d_scratch,
-                       d_trig, rot, ab, mirror, prm, (int)nb, (int)W, (int)b0, (int)n_rows);
+    const dim3 grid((unsigned)((nb * W + 255) / 256));
+    if (p->sep->kernel_nmax == 20)
+      hipLaunchKernelGGL(zk_maps_planes_kernel<20>, grid, dim3(256), 0, s, p->d_scratch, d_trig, rot, ab, mirror, prm,
+                         (int)nb, (int)W, (int)b0, (int)n_rows);
+    else
+      hipLaunchKernelGGL(zk_maps_planes_kernel<24>, grid, dim3(256), 0, s, p->d_scratch, d_trig, rot, ab, mirror, prm,
+                         (int)nb, (int)W, (int)b0, (int)n_rows);
     ZK_HIP(hipGetLastError());
     if ((rc = zk_prof_end(p, s))) return rc;
   }

@@ -1,7 +1,7 @@
 // zk_sep_patches.hip -- batch-of-patches Zernike moments (reference _zps.py:146-157): HBM-streaming,
 // LDS-DMA transposed, row-separable arithmetic.  float32 patches of any size K >= 16 and float64 patches
-// of any size K >= 8, odd sizes included (LDS-DMA sources only need element alignment); n_max <= 20
-// (17-20: one launch per mirror-parity class, see MASK below).
+// of any size K >= 8, odd sizes included (LDS-DMA sources only need element alignment); n_max <= 24
+// (17-24: one launch per mirror-parity class, see MASK below).
 // (Large batches of sizes that get no whole-line units here go to zk_sep_stream.hip under ZK_PATH_AUTO.)
 //
 // Work decomposition.  One wave owns 64 consecutive patches, one patch per lane, and keeps that
@@ -41,7 +41,7 @@
 
 // Build groups: the kernel instances are spread over several translation units (Makefile) so that they
 // compile in parallel: group 0 = n_max kernels 4..12 (and every non-template entry point), 1 = 14 / 16,
-// 2 = 20 (class-pass kernels).  Group 0's launcher forwards to the others.
+// 2 = 20 / 24 (class-pass kernels).  Group 0's launcher forwards to the others.
 #ifndef ZK_NMAX_GROUP
 #define ZK_NMAX_GROUP 0
 #endif
@@ -373,8 +373,10 @@ int ZK_GROUP_FN(zk_launch_sep_patches)(zk_plan* p, const void* in, int dtype, in
   if (p->sep->kernel_nmax > 12) return zk_launch_sep_patches_g1(p, in, dtype, n_patches, out, s);
 #endif
 #if ZK_NMAX_GROUP == 2
-  if (dtype == ZK_F32) return launch_passes<20, float>(p, in, n_patches, out, s);
-  return launch_passes<20, double>(p, in, n_patches, out, s);
+  const bool f32 = dtype == ZK_F32;
+  if (p->sep->kernel_nmax == 20)
+    return f32 ? launch_passes<20, float>(p, in, n_patches, out, s) : launch_passes<20, double>(p, in, n_patches, out, s);
+  return f32 ? launch_passes<24, float>(p, in, n_patches, out, s) : launch_passes<24, double>(p, in, n_patches, out, s);
 #else
   if (dtype == ZK_F64)
     return p->sep->batch[1].wide ? launch_run<8, double, true>(p, in, n_patches, out, s)

@@ -28,7 +28,7 @@
 
 // Build groups: the kernel instances are spread over several translation units (Makefile) so that they
 // compile in parallel: group 0 = n_max kernels 4..12 (and every non-template entry point), 1 = 14 / 16,
-// 2 = 20 (class-pass kernels).  Group 0's launcher forwards to the others.
+// 2 = 20 / 24 (class-pass kernels).  Group 0's launcher forwards to the others.
 #ifndef ZK_NMAX_GROUP
 #define ZK_NMAX_GROUP 0
 #endif

@@ -132,7 +132,7 @@ def test_moments_at_key_points(native, zo):
         ref = zo.moments_patches(patches, z.polynomials)
         got = z.transform_at(frame, pts)
         assert got.data.shape == ref.shape and got.patch_size == size
-        rel_close(got.data, ref, atol_scale=1e-8 if n_max > 16 else 1e-10 if n_max > 12 else 1e-11 if n_max > 10 else 1e-12)
+        rel_close(got.data, ref, atol_scale=3e-7 if n_max > 20 else 1e-8 if n_max > 16 else 1e-10 if n_max > 12 else 1e-11 if n_max > 10 else 1e-12)
     z = _zps(8, 32)
     frame = rng.random((64, 64)).astype(np.float32)
     edge = z.transform_at(frame, [[0, 0], [63, 63], [5, 60]]).data                       # zero padding outside
@@ -188,7 +188,8 @@ def test_fused_symmetry_maps(native, golden, zo):
                                       (5, 16, (33, 65), np.float32), (7, 33, (40, 50), np.float32),
                                       (12, 40, (50, 70), np.float32), (14, 32, (40, 60), np.float32),
                                       (16, 36, (44, 48), np.float64),
-                                      (18, 40, (45, 50), np.float32), (20, 44, (50, 47), np.float64)]:
+                                      (18, 40, (45, 50), np.float32), (20, 44, (50, 47), np.float64),
+                                      (23, 48, (50, 52), np.float32)]:
         zz = _zps(n_max, size)
         frame = (rng.random(shape) + 0.1).astype(dtype)
         zm = zz.transform(frame)
@@ -260,7 +261,7 @@ def test_patches_ragged_counts(native, zo, n_patches):
     # n_max 13-16 (the reference's estimate_n_max returns at least 12, _estimate_n_max.py:95): kernels 14 / 16
     (13, 32, np.float32), (14, 32, np.float32), (16, 32, np.float32), (15, 48, np.float32), (16, 33, np.float32),
     (14, 64, np.float32), (16, 72, np.float64), (16, 40, np.float64),
-    # n_max 17-20: one pass per mirror-parity class (kernel 20); above that the generic kernel
+    # n_max 17-24: one pass per mirror-parity class (kernels 20 / 24); above that the generic kernel
     (17, 36, np.float32), (18, 40, np.float32), (20, 48, np.float32), (22, 48, np.float64), (24, 56, np.float32),
     (19, 39, np.float32), (24, 64, np.float64), (25, 56, np.float32),
 ])
@@ -271,13 +272,14 @@ def test_patches_shapes_vs_oracle(native, zo, n_max, size, dtype):
     ref = zo.moments_patches(p, z.polynomials)
     res = _both_paths(native, z, p, 0)
     if n_max > 12:
-        assert ("separable" in res) == (n_max <= 20) and ("stream" in res) == (n_max <= 16)
+        assert ("separable" in res) == (n_max <= 24) and ("stream" in res) == (n_max <= 16)
     for name, got in res.items():
         # the separable paths' T entries grow with n_max: ~1e-12 * max|Z| of rounding at 11-12, ~1e-11 at 16
-        # (~1e-9 at 17-20, where the reference's own float64 basis carries ~1e-9 of rounding)
+        # (17-24: the reference's own float64 basis carries ~1e-9 (n_max 20) .. 3e-8 (24) of rounding against
+        # the exact polynomial the kernels use; the north star's tolerance is 1e-6)
         fast = name in ("separable", "stream")
-        rel_close(got, ref, atol_scale=1e-8 if (fast and n_max > 16) else 1e-10 if (fast and n_max > 12) else
-                  1e-11 if (fast and n_max > 10) else 1e-12)
+        rel_close(got, ref, atol_scale=3e-7 if (fast and n_max > 20) else 1e-8 if (fast and n_max > 16) else
+                  1e-10 if (fast and n_max > 12) else 1e-11 if (fast and n_max > 10) else 1e-12)
 
 
 @pytest.mark.parametrize("n_max,size,shape,dtype", [
@@ -289,7 +291,7 @@ def test_patches_shapes_vs_oracle(native, zo, n_max, size, dtype):
     (14, 32, (45, 70), np.float32), (16, 32, (64, 64), np.float64), (16, 48, (50, 130), np.float32),
     (13, 33, (40, 40), np.float32),
     (18, 40, (50, 70), np.float32), (20, 44, (44, 60), np.float64), (24, 50, (60, 66), np.float32),
-    (21, 45, (50, 50), np.float32),
+    (21, 45, (50, 50), np.float32), (25, 52, (56, 60), np.float32),
 ])
 def test_frame_shapes_vs_oracle(native, zo, n_max, size, shape, dtype):
     rng = np.random.default_rng(size * 1000 + shape[0])
@@ -299,8 +301,8 @@ def test_frame_shapes_vs_oracle(native, zo, n_max, size, shape, dtype):
     for name, got in _both_paths(native, z, img, 1).items():
         # the separable path's T entries grow with n_max: ~1e-12 * max|Z| of rounding at n_max 11-12, ~1e-11 at 16
         sep = name == "separable"
-        rel_close(got, ref, atol_scale=1e-8 if (sep and n_max > 16) else 1e-10 if (sep and n_max > 12) else
-                  1e-11 if (sep and n_max > 10) else 1e-12)
+        rel_close(got, ref, atol_scale=3e-7 if (sep and n_max > 20) else 1e-8 if (sep and n_max > 16) else
+                  1e-10 if (sep and n_max > 12) else 1e-11 if (sep and n_max > 10) else 1e-12)
 
 
 @pytest.mark.parametrize("n_max,size,dtype", [(6, 24, np.float32), (8, 33, np.float32), (10, 12, np.float64)])
@@ -397,7 +399,7 @@ def test_c_abi_argument_errors(native):
                               z.polynomials.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 99,
                               ctypes.byref(handle)) == -10001                     # bad device index
     with pytest.raises(RuntimeError, match="not available"):
-        big = _zps(21, 64)._device_plan()                                          # no fast tables above n_max 20
+        big = _zps(25, 64)._device_plan()                                          # no fast tables above n_max 24
         big.set_path(native.PATH_SEPARABLE)
         big.transform_patches(np.zeros((2, 64, 64), np.float32))
 
