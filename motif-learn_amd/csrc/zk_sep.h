@@ -140,6 +140,7 @@ struct zk_sep_unit {    // batch kernel: 16 (float32) / 8 (float64) quadrant col
                         // belongs to the second row (K-1-r) of the pair; bits 8..: cmax = ceil(K/2)
 };
 
+#define ZK_STREAM_ROW(NMAX) (((NMAX) + 1) & ~1)  // doubles per row of the stream kernel's table (P_1 .. P_NMAX)
 #define ZK_STREAM_PAD 4  // zero rows either side of the stream kernel's Legendre table (one granule of pixels)
 
 // Stream ("flat") batch kernel, zk_sep_stream.hip: a patch is read as the contiguous pixel stream it is
@@ -182,7 +183,7 @@ struct zk_sep_tables {
   };
   batch_tables batch[2];
   // stream batch kernel: full-width Legendre table + row / line lists per element type
-  double* d_pfull_alloc = nullptr;    // ZK_STREAM_PAD zero rows | [K][ZK_SEP_ROW] | ZK_STREAM_PAD zero rows
+  double* d_pfull_alloc = nullptr;    // ZK_STREAM_PAD zero rows | [K][ZK_STREAM_ROW(kernel n_max)] | ZK_STREAM_PAD zero rows
   double* d_pfull = nullptr;          // row 0 of it: P_1(x_c) .. P_nmax(x_c) for column c (P_0 = 1 is implicit)
   struct stream_tables {
     int n_units = 0;

@@ -295,11 +295,12 @@ int zk_sep_build(zk_plan* p, const double* basis) {
 
   // ---- stream batch kernel (zk_sep_stream.hip): full-width table, disk rows and 128-B lines -------
   {
-    std::vector<double> pfull((size_t)(K + 2 * ZK_STREAM_PAD) * ZK_SEP_ROW, 0.0);
+    const int srow = ZK_STREAM_ROW(knm);
+    std::vector<double> pfull((size_t)(K + 2 * ZK_STREAM_PAD) * srow, 0.0);
     for (int c = 0; c < K; ++c)
-      for (int a = 1; a < D; ++a) pfull[(size_t)(c + ZK_STREAM_PAD) * ZK_SEP_ROW + a - 1] = (double)P[(size_t)c * D + a];
+      for (int a = 1; a < D; ++a) pfull[(size_t)(c + ZK_STREAM_PAD) * srow + a - 1] = (double)P[(size_t)c * D + a];
     if ((rc = upload(&t->d_pfull_alloc, pfull))) return rc;
-    t->d_pfull = t->d_pfull_alloc + ZK_STREAM_PAD * ZK_SEP_ROW;
+    t->d_pfull = t->d_pfull_alloc + ZK_STREAM_PAD * srow;
     std::vector<zk_stream_row> srows;
     for (int r = 0; r < K; ++r) {
       int lo = -1, hi = -1;

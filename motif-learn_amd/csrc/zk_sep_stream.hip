@@ -57,6 +57,9 @@ __global__ __launch_bounds__(ZK_STREAM_WG, (NMAX <= 12 ? 2 : 1)) void zk_patch_s
     const int32_t* __restrict__ colmap, int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp,
     int K, int aligned) {
   using S = zk_sep_set<NMAX>;
+  // table rows are packed (P_1 .. P_NMAX, NMAX even): with a power-of-two row pitch the rows of a wide patch
+  // fall into a fraction of the scalar cache's sets and evict each other
+  constexpr int SROW = ZK_STREAM_ROW(NMAX);
   constexpr int PXG = 16 / sizeof(TIN);  // pixels per 16-B granule: 4 (float32) or 2 (float64)
   typedef TIN gran_t __attribute__((ext_vector_type(PXG)));
   __shared__ __attribute__((aligned(16))) float lds[ZK_STREAM_WPB * 4096];  // 2 x 8 KiB per wave
@@ -115,21 +118,21 @@ __global__ __launch_bounds__(ZK_STREAM_WG, (NMAX <= 12 ? 2 : 1)) void zk_patch_s
   const ZK_CONST int32_t* rtab = zk_const((const int32_t*)rows);  // 4 ints per row: ts, te, r, -
 
   // stream position: the current disk row (flat pixels ts..te, row rr) and the start of the one after it.
-  // xcur + t * ZK_SEP_ROW is the Legendre row of pixel t of the current row (its column is t - rr * K).
+  // xcur + t * SROW is the Legendre row of pixel t of the current row (its column is t - rr * K).
   int ri = -1, ts = 0, te = -1, rr = 0, nts = 0, nte = -1, nrr = 0;
   const ZK_CONST double* xcur = pf;
-  const ZK_CONST double* const zrow = pf + K * ZK_SEP_ROW;  // all zeros: pixels outside the disk
+  const ZK_CONST double* const zrow = pf + K * SROW;  // all zeros: pixels outside the disk
   auto load_rows = [&](int i) {
     ri = i;
     ts = rtab[4 * i], te = rtab[4 * i + 1], rr = rtab[4 * i + 2];
     nts = rtab[4 * i + 4], nte = rtab[4 * i + 5], nrr = rtab[4 * i + 6];
-    xcur = pf - rr * K * ZK_SEP_ROW;
+    xcur = pf - rr * K * SROW;
   };
   auto next_row = [&]() {
     ++ri;
     ts = nts, te = nte, rr = nrr;
     nts = rtab[4 * ri + 4], nte = rtab[4 * ri + 5], nrr = rtab[4 * ri + 6];
-    xcur = pf - rr * K * ZK_SEP_ROW;
+    xcur = pf - rr * K * SROW;
   };
 
   const int off = (int)((wave_id * 7) % n_units);  // first line of this wave (channel spreading)
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(ZK_STREAM_WG, (NMAX <= 12 ? 2 : 1)) void zk_patch_s
     const int u = unit_at(k);
     const int t0 = utab[4 * u + 1], urow = utab[4 * u + 2];
     if (urow != ri) {  // first unit, or the wrap-around of a rotated start: flush the row in progress
-      if (ri >= 0) acc.stream_row_end(X, pf + rr * ZK_SEP_ROW);
+      if (ri >= 0) acc.stream_row_end(X, pf + rr * SROW);
       load_rows(urow);
     }
     if (k + 1 < n_units) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // unit k landed, k + 1 in flight
@@ -176,12 +179,12 @@ __global__ __launch_bounds__(ZK_STREAM_WG, (NMAX <= 12 ? 2 : 1)) void zk_patch_s
 #pragma unroll
           for (int e = 0; e < PXG; ++e) vm[e] = (tg + e >= ts && tg + e <= te) ? v[e] : (TIN)0;
         }
-        const ZK_CONST double* base = xcur + tg * ZK_SEP_ROW;
+        const ZK_CONST double* base = xcur + tg * SROW;
         double xv[PXG][S::NA - 1];
 #pragma unroll
         for (int e = 0; e < PXG; ++e)
 #pragma unroll
-          for (int i = 0; i < S::NA - 1; ++i) xv[e][i] = base[e * ZK_SEP_ROW + i];
+          for (int i = 0; i < S::NA - 1; ++i) xv[e][i] = base[e * SROW + i];
 #pragma unroll
         for (int e = 0; e < PXG; ++e) {
           const double f = (double)vm[e];
@@ -191,13 +194,13 @@ __global__ __launch_bounds__(ZK_STREAM_WG, (NMAX <= 12 ? 2 : 1)) void zk_patch_s
         }
         if (te < tg + PXG) {  // the current row ends in this granule; pixels behind its end may already
                               // belong to the next row (a granule touches at most two rows: a row is longer)
-          acc.stream_row_end(X, pf + rr * ZK_SEP_ROW);
+          acc.stream_row_end(X, pf + rr * SROW);
           next_row();
 #pragma unroll
           for (int e = 1; e < PXG; ++e) {
             const int t = tg + e;
             const bool in = t >= ts && t <= te;
-            const ZK_CONST double* xn = in ? xcur + t * ZK_SEP_ROW : zrow;
+            const ZK_CONST double* xn = in ? xcur + t * SROW : zrow;
             const double f = (double)(in ? v[e] : (TIN)0);
             X[0] += f;
 #pragma unroll
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(ZK_STREAM_WG, (NMAX <= 12 ? 2 : 1)) void zk_patch_s
     if (k + 2 < n_units) issue(unit_at(k + 2), k & 1);
 #endif
   }
-  acc.stream_row_end(X, pf + rr * ZK_SEP_ROW);
+  acc.stream_row_end(X, pf + rr * SROW);
 
   // ---- Z = T M, then (patch, column) rows via LDS -> 16-B stores ------------------------------------
   double z[S::NP];
