@@ -97,12 +97,14 @@ static int build_generic_tables(zk_plan* p, const double* basis) {
       if (any) pix.push_back(make_int2(r, c));
     }
   p->npx = (int)pix.size();
-  p->n_chunks = (NP + ZK_GEN_CHUNK - 1) / ZK_GEN_CHUNK;
-  std::vector<double> tab((size_t)p->n_chunks * p->npx * ZK_GEN_CHUNK, 0.0);
+  p->gen_chunk = NP <= 64 ? 64 : 32;
+  const int CH = p->gen_chunk;
+  p->n_chunks = (NP + CH - 1) / CH;
+  std::vector<double> tab((size_t)p->n_chunks * p->npx * CH, 0.0);
   for (int j = 0; j < NP; ++j) {
-    const int c = j / ZK_GEN_CHUNK, l = j % ZK_GEN_CHUNK;
+    const int c = j / CH, l = j % CH;
     for (int t = 0; t < p->npx; ++t)
-      tab[((size_t)c * p->npx + t) * ZK_GEN_CHUNK + l] =
+      tab[((size_t)c * p->npx + t) * CH + l] =
           basis[((size_t)j * K + pix[t].x) * K + pix[t].y] * inv_area;
   }
   if (p->npx == 0) return 0;

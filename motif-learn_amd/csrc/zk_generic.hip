@@ -2,7 +2,7 @@
 //
 // One lane owns one output unit (a patch in batch mode, an output pixel in frame mode) and
 // walks the disk pixels in row-major order.  The loop index is wave-uniform, so the pixel
-// coordinates and the ZK_GEN_CHUNK basis values of the current pixel come in through scalar
+// coordinates and the CHUNK basis values of the current pixel come in through scalar
 // loads (SGPR operands of v_fma_f64) and cost no vector-memory or LDS bandwidth; the only
 // per-lane traffic is the pixel itself.  In frame mode consecutive lanes read consecutive
 // image columns (coalesced, L2-resident frame); in batch mode lanes are one patch apart,
@@ -15,7 +15,7 @@
 
 namespace {
 
-template <typename T, int MODE>  // MODE 0: batch of patches, 1: dense frame
+template <typename T, int MODE, int CHUNK>  // MODE 0: batch of patches, 1: dense frame; CHUNK: functions per pass
 __global__ __launch_bounds__(256) void zk_generic_kernel(
     const T* __restrict__ in, double* __restrict__ out, const int2* __restrict__ pix,
     const double* __restrict__ tab, int npx, int n_poly, int n_chunks, int size, long long n_units,
@@ -34,10 +34,10 @@ __global__ __launch_bounds__(256) void zk_generic_kernel(
   }
 
   for (int c = 0; c < n_chunks; ++c) {
-    double acc[ZK_GEN_CHUNK];
+    double acc[CHUNK];
 #pragma unroll
-    for (int j = 0; j < ZK_GEN_CHUNK; ++j) acc[j] = 0.0;
-    const double* __restrict__ row = tab + (size_t)c * npx * ZK_GEN_CHUNK;
+    for (int j = 0; j < CHUNK; ++j) acc[j] = 0.0;
+    const double* __restrict__ row = tab + (size_t)c * npx * CHUNK;
     for (int t = 0; t < npx; ++t) {
       const int2 rc = pix[t];
       double f;
@@ -49,14 +49,14 @@ __global__ __launch_bounds__(256) void zk_generic_kernel(
       } else {
         f = (double)base[rc.x * size + rc.y];
       }
-      const double* __restrict__ b = row + (size_t)t * ZK_GEN_CHUNK;
+      const double* __restrict__ b = row + (size_t)t * CHUNK;
 #pragma unroll
-      for (int j = 0; j < ZK_GEN_CHUNK; ++j) acc[j] = __builtin_fma(f, b[j], acc[j]);
+      for (int j = 0; j < CHUNK; ++j) acc[j] = __builtin_fma(f, b[j], acc[j]);
     }
     if (live) {
 #pragma unroll
-      for (int j = 0; j < ZK_GEN_CHUNK; ++j) {
-        const int jj = c * ZK_GEN_CHUNK + j;
+      for (int j = 0; j < CHUNK; ++j) {
+        const int jj = c * CHUNK + j;
         if (jj < n_poly) {
           if (MODE == 1) {
             // (n_poly, n_rows, W): u already enumerates (row, col) of the band
@@ -94,15 +94,17 @@ int launch(zk_plan* p, const void* in, int dtype, long long n_units, int H, int 
   if (blocks > 0x7fffffffLL) return zk_fail(ZK_E_BADARG, "too many units for one launch");
   int rc = zk_prof_begin(p, s);
   if (rc) return rc;
+#define ZK_GEN_LAUNCH(T, CH)                                                                              \
+  hipLaunchKernelGGL((zk_generic_kernel<T, MODE, CH>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)in, out, \
+                     p->d_pix, p->d_gen_tab, p->npx, p->n_poly, p->n_chunks, p->size, n_units, H, W, row0)
   if (dtype == ZK_F32) {
-    hipLaunchKernelGGL((zk_generic_kernel<float, MODE>), dim3((unsigned)blocks), dim3(256), 0, s,
-                       (const float*)in, out, p->d_pix, p->d_gen_tab, p->npx, p->n_poly, p->n_chunks,
-                       p->size, n_units, H, W, row0);
+    if (p->gen_chunk == 64) ZK_GEN_LAUNCH(float, 64);
+    else ZK_GEN_LAUNCH(float, 32);
   } else {
-    hipLaunchKernelGGL((zk_generic_kernel<double, MODE>), dim3((unsigned)blocks), dim3(256), 0, s,
-                       (const double*)in, out, p->d_pix, p->d_gen_tab, p->npx, p->n_poly, p->n_chunks,
-                       p->size, n_units, H, W, row0);
+    if (p->gen_chunk == 64) ZK_GEN_LAUNCH(double, 64);
+    else ZK_GEN_LAUNCH(double, 32);
   }
+#undef ZK_GEN_LAUNCH
   ZK_HIP(hipGetLastError());
   return zk_prof_end(p, s);
 }

@@ -9,7 +9,10 @@
 
 #include "zernike_hip.h"
 
-#define ZK_GEN_CHUNK 16  // basis functions per accumulation pass of the generic kernel
+// basis functions per accumulation pass of the generic kernel: 64 when the whole set fits one pass, else 32
+// (batch (56, n_max 25): 25.9 ms at 16 -> 13.6 at 32 -> 12.8 at 64; batch (32, 8): 14.5 -> 9.8 -> 2.6;
+//  dense (56, 25): 37.0 -> 26.7 -> 43.1)
+#define ZK_GEN_CHUNK_MAX 64
 
 // Parity class of a real Zernike function under the mirrors x -> -x and y -> -y
 // (cos(m t): x-parity (-1)^m, y-even; sin(|m| t): x-parity -(-1)^m, y-odd).
@@ -28,9 +31,10 @@ struct zk_plan {
 
   // ---- generic (unfolded) tables -------------------------------------------------
   int npx = 0;                   // pixels with a non-zero basis value (the rho<=1 disk)
-  int n_chunks = 0;              // ceil(n_poly / ZK_GEN_CHUNK)
+  int gen_chunk = 32;            // 32 or 64 (see ZK_GEN_CHUNK_MAX)
+  int n_chunks = 0;              // ceil(n_poly / gen_chunk)
   int2* d_pix = nullptr;         // [npx] (row, col) of each disk pixel, row-major order
-  double* d_gen_tab = nullptr;   // [n_chunks][npx][ZK_GEN_CHUNK], basis/area, zero padded
+  double* d_gen_tab = nullptr;   // [n_chunks][npx][gen_chunk], basis/area, zero padded
 
   // ---- parity-folded tables (fast kernels) ----------------------------------------
   zk_fold_tables* fold = nullptr;  // nullptr when the basis lacks the mirror parities
