@@ -432,6 +432,28 @@ def test_size_sweep_fast_paths_agree_with_generic(native):
     assert checked > 500
 
 
+def test_random_plans_every_family_agrees_with_generic(native):
+    """Seeded random (size, n_max <= 24, dtype, N, frame shape): every kernel family a plan offers -- row-pair,
+    stream, class-pass, folded, one- or two-wave builds of every n_max kernel -- against the generic kernel."""
+    rng = np.random.default_rng(77)
+    families = set()
+    for _ in range(60):
+        size = int(rng.integers(8, 81))
+        n_max = int(min(size, rng.integers(0, 25)))
+        dtype = np.float32 if rng.random() < 0.6 else np.float64
+        z = _zps(n_max, size)
+        p = (rng.random((int(rng.integers(1, 200)), size, size)) - 0.4).astype(dtype)
+        img = (rng.random((int(rng.integers(size, size + 40)), int(rng.integers(size, size + 100)))) - 0.4).astype(dtype)
+        floor = 3e-7 if n_max > 20 else 1e-8 if n_max > 16 else 1e-10 if n_max > 12 else 1e-11 if n_max > 10 else 1e-12
+        for out in (_both_paths(native, z, p, 0), _both_paths(native, z, img, 1)):
+            ref = out["generic"]
+            for name, got in out.items():
+                if name != "generic":
+                    assert np.abs(got - ref).max() <= floor * np.abs(ref).max(), (size, n_max, dtype, name)
+                    families.add(name)
+    assert families == {"separable", "stream", "folded"}
+
+
 def test_plain_c_client(native, zo, tmp_path):
     """The C ABI from a C program (gcc, no Python in that process): tests/c_abi_check.c."""
     import os
