@@ -429,9 +429,12 @@ __device__ __forceinline__ void zk_batch_store_rows(const double (&z)[NP], const
 }
 
 // One row pair of the dense kernels: quadrant columns cmin..Q-1 of the LDS-resident window rows `top`
-// (row r) and `bot` (row K-1-r).  Two pixels per iteration through four running pointers, so the loop
-// spends 4 integer adds per 2 pixels on addressing and the second pixel's LDS reads and scalar row
-// overlap the first pixel's FMAs.
+// (row r) and `bot` (row K-1-r).  Four (then two, then one) pixels per iteration through four running
+// pointers, so the loop spends few integer adds on addressing (they cost v_fma_f64 issue slots) and the
+// later pixels' LDS reads and scalar rows overlap the first pixel's FMAs.
+#ifndef ZK_ROW_PAIR_UNROLL4
+#define ZK_ROW_PAIR_UNROLL4 1  // (-1 % at (32, 8), -5 % at (64, 12) per dense frame)
+#endif
 template <int NMAX, int MASK>
 __device__ __forceinline__ void zk_sep_row_pair(zk_sep_acc<NMAX, MASK>& acc, const double* __restrict__ top,
                                                 const double* __restrict__ bot, int cmin, int Q, int K,
@@ -442,6 +445,19 @@ __device__ __forceinline__ void zk_sep_row_pair(zk_sep_acc<NMAX, MASK>& acc, con
   const double* bb = bot + (K - 1 - cmin);
   const ZK_CONST double* pr = px + cmin * ZK_SEP_ROW;
   int c = cmin;
+#if ZK_ROW_PAIR_UNROLL4
+  for (; c + 3 < Q; c += 4) {  // four pixels per pointer update (the integer adds cost v_fma_f64 issue slots)
+    acc.pixel(tf[0], tb[0], bf[0], bb[0], pr);
+    acc.pixel(tf[1], tb[-1], bf[1], bb[-1], pr + ZK_SEP_ROW);
+    acc.pixel(tf[2], tb[-2], bf[2], bb[-2], pr + 2 * ZK_SEP_ROW);
+    acc.pixel(tf[3], tb[-3], bf[3], bb[-3], pr + 3 * ZK_SEP_ROW);
+    tf += 4;
+    tb -= 4;
+    bf += 4;
+    bb -= 4;
+    pr += 4 * ZK_SEP_ROW;
+  }
+#endif
   for (; c + 1 < Q; c += 2) {
     acc.pixel(tf[0], tb[0], bf[0], bb[0], pr);
     acc.pixel(tf[1], tb[-1], bf[1], bb[-1], pr + ZK_SEP_ROW);
