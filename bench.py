@@ -49,7 +49,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-frame side measurement")
     ap.add_argument("--no-maps", action="store_true", help="skip the configs[4] symmetry-map side measurement")
-    ap.add_argument("--no-4096", action="store_true", help="skip the north-star 4096^2 batch side measurement")
+    ap.add_argument("--with-4096", action="store_true",
+                    help="also time the north star's own size (all windows of a 4096^2 frame, 67.7 GB) -- opt-in: it "
+                         "launches the same kernel as the timed loop and would skew a rocprofv3 --stats average")
     return ap.parse_args()
 
 
@@ -328,7 +330,7 @@ def main():
         del big
 
     # ---- north star's own size: all dense 32-px windows of a 4096^2 frame as one batch (side measurement) --
-    if world == 1 and not args.no_4096 and K == 32:
+    if world == 1 and args.with_4096 and K == 32:
         try:
             del patches, outs                                            # (already gone if the maps section ran)
         except NameError:
