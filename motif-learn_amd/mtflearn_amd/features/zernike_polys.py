@@ -198,16 +198,17 @@ class ZPs(BaseEstimator, TransformerMixin):
 
     def symmetry_maps(self, image, n_folds=(2, 3, 4, 6), p=2, m_unselect=(0, 1), theta=None,
                       abs_moments=True, mirror=True):
-        """Frame -> symmetry maps in one fused pass on the GPU (extension; not in the reference API).
+        """Frame -> symmetry maps on the GPU, one fused kernel up to n_max 16 (extension; not in the reference API).
 
         Equivalent to ``zm = self.transform(image)`` followed by ``zm.rot_maps(n_folds, p, m_unselect)``,
         ``np.abs(zm.to_complex().data)`` and ``zm.mirror_map(theta, p, m_unselect)`` (reference
-        ``_zmoments.py:300-316, 420-493``), but the ``(N_poly, H, W)`` moments never leave the chip.
+        ``_zmoments.py:300-316, 420-493``), but the ``(N_poly, H, W)`` moments never leave the GPU (n_max 17-24:
+        they pass through a device scratch matrix, a row band at a time).
         Returns a dict with ``rot_maps (len(n_folds), H, W)``, ``abs (N_c, H, W)`` with its ``abs_n`` /
         ``abs_m`` labels, ``mirror_map (H, W)`` (entries present only when requested) and ``valid_mask``.
         Falls back to the unfused composition (device transform + the container's NumPy methods) for
         shapes or options the fused kernel does not cover (``p`` other than 2 / None, more than 8 folds,
-        n_max > 10, odd tail cases where the separable tables are unavailable)."""
+        n_max > 24, shapes for which the separable tables are unavailable)."""
         image = np.asarray(image)
         if image.ndim != 2:
             raise ValueError("symmetry_maps needs a 2D image.")
