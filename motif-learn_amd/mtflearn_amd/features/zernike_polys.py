@@ -132,7 +132,12 @@ class ZPs(BaseEstimator, TransformerMixin):
         if np.iscomplexobj(images):
             raise TypeError("complex images are not supported by the HIP kernels")
         if images.dtype not in (np.float32, np.float64):
-            images = images.astype(np.float64)  # ints, bool, float16: exact in float64
+            # what NumPy's promotion to float64 would compute: bool, float16 and integers of up to 16 bits
+            # (the usual detector formats) are exact in float32 as well -- half the bytes to move and the
+            # float32 kernels; wider integers go to float64
+            narrow = images.dtype == np.bool_ or images.dtype == np.float16 or \
+                (images.dtype.kind in "iu" and images.dtype.itemsize <= 2)
+            images = images.astype(np.float32 if narrow else np.float64)
         return np.ascontiguousarray(images)
 
     # ------------------------------------------------------------------ transform

@@ -86,6 +86,13 @@ def test_patches_api_dtypes_and_layouts(golden):
     rel_close(z8.transform(p[::-1]).data, golden["Z_rand_f32_8_32"][::-1])
     rel_close(z8.transform(p.astype(np.float64)).data, golden["Z_rand_f32_8_32"])
     rel_close(z8.fit_transform(p).data, golden["Z_rand_f32_8_32"])
+    # detector formats: uint16 / int16 / bool go through float32 exactly -> the same moments as their float64 copies
+    rng = np.random.default_rng(5)
+    u16 = rng.integers(0, 65536, size=(70, 32, 32), dtype=np.uint16)
+    np.testing.assert_array_equal(z8.transform(u16).data, z8.transform(u16.astype(np.float32)).data)
+    rel_close(z8.transform(u16).data, z8.transform(u16.astype(np.float64)).data)
+    frame16 = rng.integers(-3000, 3000, size=(40, 50)).astype(np.int16)
+    rel_close(z8.transform(frame16).data, z8.transform(frame16.astype(np.float64)).data)
 
 
 # ------------------------------------------------------------------ golden vectors: dense path

@@ -226,6 +226,20 @@ def _declared_symbols():
     return sorted(set(re.findall(r"\b(zk_[a-z_0-9]+)\s*\(", text)))
 
 
+def test_device_operand_dtypes():
+    """Narrow detector formats go to float32 (exact), wide integers to float64, as NumPy's promotion would give."""
+    from mtflearn_amd import ZPs
+    for dt, want in [(np.uint8, np.float32), (np.int16, np.float32), (np.uint16, np.float32), (np.bool_, np.float32),
+                     (np.float16, np.float32), (np.int32, np.float64), (np.uint32, np.float64), (np.int64, np.float64),
+                     (np.float32, np.float32), (np.float64, np.float64)]:
+        a = (np.arange(24).reshape(4, 6) % 2 if dt == np.bool_ else np.arange(24).reshape(4, 6) * 997 % 251).astype(dt)
+        op = ZPs._device_operand(a[:, ::2])
+        assert op.dtype == want and op.flags.c_contiguous
+        np.testing.assert_array_equal(op.astype(np.float64), a[:, ::2].astype(np.float64))
+    with pytest.raises(TypeError):
+        ZPs._device_operand(np.zeros((2, 2), np.complex64))
+
+
 def test_library_exports_every_declared_symbol():
     if not os.path.exists(_native.LIB_PATH):
         import __graft_entry__
