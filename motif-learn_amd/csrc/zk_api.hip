@@ -4,6 +4,8 @@
 
 #include <new>
 
+#include <stdlib.h>
+
 #include "zk_internal.h"
 
 // ------------------------------------------------------------------------------------
@@ -258,6 +260,10 @@ extern "C" int zk_transform_frame_dev(zk_plan* p, const void* image, int dtype, 
   hipStream_t s = (hipStream_t)hip_stream;  // exactly the caller's stream; NULL is HIP's default stream
   const int path = resolve_path(p, 1, dtype);
   if (path < 0) return zk_fail(ZK_E_BADARG, "the forced kernel path is not available for this plan / dtype");
+  // n_max <= 8 and windows up to 65 px: the strip form of the dense kernel (two outputs per lane, zk_sep_strip.hip);
+  // ZK_NO_STRIP in the environment keeps the one-output kernel (A/B measurements, tests)
+  if (path == ZK_PATH_SEPARABLE && zk_sep_strip_available(p, dtype) && !getenv("ZK_NO_STRIP"))
+    return zk_launch_sep_strip(p, image, dtype, H, W, row0, n_rows, out, s);
   if (path == ZK_PATH_SEPARABLE) return zk_launch_sep_frame(p, image, dtype, H, W, row0, n_rows, out, s);
   if (path == ZK_PATH_FOLDED) return zk_launch_fast_frame(p, image, dtype, H, W, row0, n_rows, out, s);
   return zk_launch_generic_frame(p, image, dtype, H, W, row0, n_rows, out, s);

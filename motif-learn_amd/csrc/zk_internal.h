@@ -94,6 +94,9 @@ int zk_sep_build(zk_plan* p, const double* basis);   // fills p->sep or leaves i
 void zk_sep_free(zk_plan* p);
 bool zk_sep_frame_available(const zk_plan* p, int dtype);
 bool zk_sep_patches_available(const zk_plan* p, int dtype);
+bool zk_sep_strip_available(const zk_plan* p, int dtype);   // zk_sep_strip.hip: dense, n_max <= 8, two outputs per lane
+int zk_launch_sep_strip(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                        double* out, hipStream_t s);
 bool zk_sep_points_available(const zk_plan* p, int dtype);  // single-pass kernels only (n_max <= 16)
 bool zk_sep_maps_available(const zk_plan* p, int dtype);
 int zk_launch_sep_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,

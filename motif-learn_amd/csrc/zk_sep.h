@@ -168,6 +168,7 @@ struct zk_sep_tables {
   int32_t* d_colmap = nullptr;     // [np_kernel] class-ordered Zernike slot -> output column or -1
   int n_rows = 0;
   zk_sep_row* d_rows = nullptr;    // [n_rows]
+  int32_t* d_cmin = nullptr;       // [K] first quadrant column inside the disk of window row r (Q: none); strip kernel
   int tile_pitch = 0;
   double* d_trig = nullptr;        // fused maps: [n_theta][2][ZK_SEP_ROW] cos / sin(m theta), per call
   size_t trig_doubles = 0;
@@ -332,6 +333,10 @@ struct zk_sep_acc : zk_sep_rows<NMAX, MASK> {
   __device__ __forceinline__ void stream_all(const double (&X)[S::NA], const ZK_CONST double* py,
                                              std::integer_sequence<int, Is...>) {
     (stream_slot<Is>(X, py), ...);
+  }
+  // the same without clearing X (strip dense kernel: the sums run on to the next, wider row)
+  __device__ __forceinline__ void stream_accumulate(const double (&X)[S::NA], const ZK_CONST double* py) {
+    stream_all(X, py, std::make_integer_sequence<int, S::NP>{});
   }
   __device__ __forceinline__ void stream_row_end(double (&X)[S::NA], const ZK_CONST double* py) {
     stream_all(X, py, std::make_integer_sequence<int, S::NP>{});

@@ -67,6 +67,7 @@ void zk_sep_free(zk_plan* p) {
   if (t->d_T) (void)hipFree(t->d_T);
   if (t->d_colmap) (void)hipFree(t->d_colmap);
   if (t->d_rows) (void)hipFree(t->d_rows);
+  if (t->d_cmin) (void)hipFree(t->d_cmin);
   for (auto& b : t->batch) {
     if (b.d_units) (void)hipFree(b.d_units);
     if (b.d_row_starts) (void)hipFree(b.d_row_starts);
@@ -220,6 +221,13 @@ int zk_sep_build(zk_plan* p, const double* basis) {
   if ((rc = upload(&t->d_colmap, colmap))) return rc;
   t->n_rows = (int)rows.size();
   if ((rc = upload(&t->d_rows, rows))) return rc;
+  {
+    std::vector<int32_t> cmin_full(K, Q);
+    for (const zk_sep_row& row : rows) cmin_full[row.r] = cmin_full[K - 1 - row.r] = row.cmin;
+    bool nested = true;  // the strip kernel relies on limits that shrink towards the centre row (a disk's do)
+    for (int r = 0; r + 1 < Q; ++r) nested = nested && cmin_full[r] >= cmin_full[r + 1];
+    if (nested && (rc = upload(&t->d_cmin, cmin_full))) return rc;
+  }
 
   // ---- batch kernel unit lists ------------------------------------------------------------------
   // A unit is UP quadrant columns c0..c0+UP-1 of one row pair (UP = 16 float32 / 8 float64 pixels = 64 B),

@@ -368,6 +368,31 @@ def test_non_finite_pixels(native, n_max, size, dtype):
             plan.set_path(native.PATH_AUTO)
 
 
+def test_strip_and_one_output_dense_kernels_agree(native, zo):
+    """n_max <= 8, windows up to 65 px: ZK_PATH_SEPARABLE runs the strip kernel (two outputs per lane);
+    ZK_NO_STRIP selects the one-output kernel.  Both against the oracle, odd / even sizes and ragged shapes."""
+    import os
+    rng = np.random.default_rng(31)
+    for n_max, size, shape, dtype in [(8, 32, (70, 131), np.float32), (7, 33, (41, 66), np.float32),
+                                      (4, 9, (17, 20), np.float64), (8, 64, (66, 70), np.float32),
+                                      (6, 65, (65, 65), np.float64), (2, 8, (9, 300), np.float32)]:
+        z = _zps(n_max, size)
+        plan = z._device_plan()
+        img = (rng.random(shape) - 0.5).astype(dtype)
+        ref = zo.moments_frame_direct(img, z.polynomials)
+        plan.set_path(native.PATH_SEPARABLE)
+        try:
+            strip = plan.transform_frame(img)
+            os.environ["ZK_NO_STRIP"] = "1"
+            single = plan.transform_frame(img)
+        finally:
+            os.environ.pop("ZK_NO_STRIP", None)
+            plan.set_path(native.PATH_AUTO)
+        rel_close(strip, ref)
+        rel_close(single, ref)
+        assert np.abs(strip - single).max() > 0   # two different kernels ran (different summation orders)
+
+
 def test_zero_and_constant_inputs(native):
     z = _zps(8, 32)
     assert not z.transform(np.zeros((5, 32, 32), np.float32)).data.any()
