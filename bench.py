@@ -267,6 +267,17 @@ def main():
             zns = [n for n in range(args.n_max + 1) for m in range(-n, n + 1, 2) if m_sel(m)]
             t_terms += sum(1 for n in zns for d in degs if d <= n)
         sep_flops = quad_px * (8 + 4 * (args.n_max + 1)) + 2 * row_pairs * n_poly + 2 * t_terms
+        # strip kernel (zk_sep_strip.hip; n_max <= 8, windows <= 65 px): per PAIR of outputs every frame row is swept
+        # once from the centre to the wider of the two inner limits (2 adds + (n_max+1) FMAs per column pair), every
+        # disk row of either output costs N_poly FMAs, and there are two T products
+        strip = args.n_max <= 8 and (K + 7) * (K + 63) * 8 <= 80 * 1024 and not os.environ.get("ZK_NO_STRIP")
+        if strip:
+            Qh = (K + 1) // 2
+            mask = z.polynomials[0] != 0
+            cmin = [int(np.argmax(mask[r, :Qh])) if mask[r, :Qh].any() else Qh for r in range(K)]
+            sweep_cols = sum(Qh - min(cmin[fr] if fr < K else Qh, cmin[fr - 1] if fr > 0 else Qh) for fr in range(K + 1))
+            disk_rows = sum(1 for c in cmin if c < Qh)
+            sep_flops = (sweep_cols * (2 + 2 * (args.n_max + 1)) + 2 * disk_rows * 2 * n_poly + 2 * 2 * t_terms) / 2
         dense = {"positions": npx, "bound": "fp64-valu", "fp64_vector_peak_TFLOPs": FP64_VECTOR_PEAK_TF,
                  "kernels": {}}
         for path in (_native.PATH_SEPARABLE, _native.PATH_FOLDED):
@@ -290,7 +301,9 @@ def main():
             if path == _native.PATH_SEPARABLE:
                 ex = npx * sep_flops / (fms * 1e-3) / 1e12
                 dense["kernels"]["separable"].update({"fp64_TFLOPs_executed": ex,
-                                                      "fp64_frac_of_peak": ex / FP64_VECTOR_PEAK_TF})
+                                                      "fp64_frac_of_peak": ex / FP64_VECTOR_PEAK_TF,
+                                                      "kernel": "zk_frame_strip_kernel" if strip else "zk_frame_sep_kernel",
+                                                      "fp64_flops_per_position": sep_flops})
         plan.set_path(_native.PATH_AUTO)
         result["dense_frame"] = dense
         del out_f
