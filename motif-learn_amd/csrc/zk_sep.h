@@ -323,19 +323,19 @@ struct zk_sep_acc : zk_sep_rows<NMAX, MASK> {
     for (int i = 0; i < S::NP; ++i) M[i] = 0.0;
   }
   // py = P_1(y_r) .. P_nmax(y_r) (the stream kernel's table has no P_0 column: P_0 = 1)
-  template <int s>
-  __device__ __forceinline__ void stream_slot(const double (&X)[S::NA], const ZK_CONST double* py) {
+  template <int s, typename PY>
+  __device__ __forceinline__ void stream_slot(const double (&X)[S::NA], const PY& py) {
     constexpr int a = S::slot_a(s), b = S::slot_b(s);  // (constexpr: otherwise evaluated at run time for large NMAX)
     if constexpr (b == 0) M[s] += X[a];
     else M[s] = __builtin_fma(py[b - 1], X[a], M[s]);
   }
-  template <int... Is>
-  __device__ __forceinline__ void stream_all(const double (&X)[S::NA], const ZK_CONST double* py,
-                                             std::integer_sequence<int, Is...>) {
+  template <typename PY, int... Is>
+  __device__ __forceinline__ void stream_all(const double (&X)[S::NA], const PY& py, std::integer_sequence<int, Is...>) {
     (stream_slot<Is>(X, py), ...);
   }
   // the same without clearing X (strip dense kernel: the sums run on to the next, wider row)
-  __device__ __forceinline__ void stream_accumulate(const double (&X)[S::NA], const ZK_CONST double* py) {
+  template <typename PY>  // py: table row pointer, or the row's values already in registers
+  __device__ __forceinline__ void stream_accumulate(const double (&X)[S::NA], const PY& py) {
     stream_all(X, py, std::make_integer_sequence<int, S::NP>{});
   }
   __device__ __forceinline__ void stream_row_end(double (&X)[S::NA], const ZK_CONST double* py) {
