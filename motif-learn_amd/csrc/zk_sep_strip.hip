@@ -12,8 +12,7 @@
 // halves; the price is the y mirror fold (rows r and K-1-r of one output come from different frame rows), so
 // the row step costs N_poly FMAs per disk row instead of per row pair.  Net at (32, 8): ~4.1 k f64
 // operations per output against ~6.3 k.  Measured per 2048^2 frame, float32 (ms, one-output kernel -> this one):
-// (32, 8) 1.17 -> 1.08, (48, 8) 2.13 -> 1.77, (56, 8) 3.03 -> 2.30, (64, 8) 3.85 -> 2.66, (32, 6) 0.90 -> 0.73,
-// (16, 4) 0.216 -> 0.203.  Two accumulator sets only fit two waves per SIMD up to n_max 8.
+// (32, 8) 1.17 -> 0.95, (48, 8) 2.13 -> 1.58, (64, 8) 3.85 -> 2.36, (32, 6) 0.90 -> 0.65.  Two accumulator sets only fit two waves per SIMD up to n_max 8.
 //
 // 256-thread workgroup = 4 waves x 2 output rows x 64 columns; the zero-padded (K+7) x (K+63) tile is staged
 // in LDS as float64, as in zk_sep_frame.hip.  Tables: the quadrant x table (d_xq), the full-width table of the
@@ -21,6 +20,11 @@
 #include "zk_sep.h"
 
 namespace {
+
+#ifndef ZK_STRIP_GROUP
+#define ZK_STRIP_GROUP 3  // column pairs per group of the sweep (2 and 3 measure alike, 4 is 4-6 % slower; one at a
+                          // time -- a scalar-memory wait per column pair -- was 12 % slower)
+#endif
 
 template <int NMAX, typename T>
 __global__ __launch_bounds__(256, 2) void zk_frame_strip_kernel(
@@ -72,36 +76,41 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip_kernel(
 #pragma unroll
     for (int i = 0; i < S::NA; ++i) X[i] = 0.0;
     const double* __restrict__ row = mine + fr * tile_pitch;
-    auto step = [&](double a, double b, const ZK_CONST double* pr) {  // one column pair (q, K-1-q)
+    auto fma_pair = [&](double a, double b, const double (&xr)[S::NA]) {  // one column pair (q, K-1-q)
       const double s = a + b, d = a - b;
 #pragma unroll
-      for (int i = 0; i < S::NA; ++i) X[i] = __builtin_fma((i & 1) ? d : s, pr[i], X[i]);
+      for (int i = 0; i < S::NA; ++i) X[i] = __builtin_fma((i & 1) ? d : s, xr[i], X[i]);
     };
-    // quadrant columns q_from down to q_to, four / two / one at a time; two running pointers so that the LDS
-    // addresses of a group are immediates (integer adds cost v_fma_f64 issue slots)
+    // quadrant columns q_from down to q_to, ZK_STRIP_GROUP at a time: the table rows of a group are requested
+    // together, ahead of its arithmetic (one scalar-memory wait per group), and two running pointers make the
+    // LDS addresses of a group immediates
     auto sweep = [&](int q_from, int q_to) {
       int q = q_from;
       const double* pa = row + q;          // walks down
       const double* pb = row + K - 1 - q;  // walks up
       const ZK_CONST double* pr = px + q * ZK_SEP_ROW;
-      for (; q - 3 >= q_to; q -= 4) {
-        step(pa[0], pb[0], pr);
-        step(pa[-1], pb[1], pr - ZK_SEP_ROW);
-        step(pa[-2], pb[2], pr - 2 * ZK_SEP_ROW);
-        step(pa[-3], pb[3], pr - 3 * ZK_SEP_ROW);
-        pa -= 4;
-        pb += 4;
-        pr -= 4 * ZK_SEP_ROW;
+      constexpr int G = ZK_STRIP_GROUP;
+      for (; q - (G - 1) >= q_to; q -= G) {
+        double xr[G][S::NA];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int i = 0; i < S::NA; ++i) xr[g][i] = pr[-g * ZK_SEP_ROW + i];
+#pragma unroll
+        for (int g = 0; g < G; ++g) fma_pair(pa[-g], pb[g], xr[g]);
+        pa -= G;
+        pb += G;
+        pr -= G * ZK_SEP_ROW;
       }
-      if (q - 1 >= q_to) {
-        step(pa[0], pb[0], pr);
-        step(pa[-1], pb[1], pr - ZK_SEP_ROW);
-        pa -= 2;
-        pb += 2;
-        pr -= 2 * ZK_SEP_ROW;
-        q -= 2;
+      for (; q >= q_to; --q) {
+        double xr[S::NA];
+#pragma unroll
+        for (int i = 0; i < S::NA; ++i) xr[i] = pr[i];
+        fma_pair(pa[0], pb[0], xr);
+        --pa;
+        ++pb;
+        pr -= ZK_SEP_ROW;
       }
-      if (q >= q_to) step(pa[0], pb[0], pr);
     };
     const int stop_a = ca < Q ? ca : cb;
     sweep(Q - 1, stop_a);
