@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- Zernike-moment hot path on MI355X (contract: see the task brief / DESIGN.md section 7).
+"""bench.py -- Zernike-moment hot path on MI355X (contract: the task brief; numbers explained in DESIGN.md section 5).
 
 A "step" is one pass of the batch-of-patches hot path (``ZPs.transform`` on a 3-D batch, reference
 ``mtflearn/features/_zps.py:146-157``) over every dense 32-px sliding window of one synthetic
 2048 x 2048 STEM-like frame per GPU (BASELINE.json configs[1]: 4 068 289 patches, n_max = 8),
-float32 patches resident in HBM, float64 moments out.  With N > 1 ranks every rank owns its own
-frame (weak scaling, no data-path collective: every output depends on one window only).  The
-single RCCL all-gather that reassembles the (N_total, 45) moment matrix on every rank is result
-assembly, not part of the per-patch computation; it is measured in the same run by a second timed
-loop of the same K steps with the all-gather inside each step (pipelined against the next step's
-kernel on RCCL's stream) and reported under "allgather" -- ``--allgather-in-step`` makes that loop
-the one `value` is taken from.
+float32 patches resident in HBM, float64 moments out.
+
+``python bench.py --gpus N`` starts its own N ranks (one process per GPU; the parent never touches the GPU);
+under ``python -m torch.distributed.run`` the ranks it is given are used as they are.  With N > 1 every rank
+owns its own frame (weak scaling, no data-path collective) and a step INCLUDES the one exchange north_star
+names: the all-gather that reassembles the (N x 4 068 289, 45) moment matrix on every rank, issued chunk by
+chunk on RCCL (``zk_allgather_rows`` inside libzernike_hip.so -- no torch.distributed) while the next
+chunk's kernel runs.  `value` is that whole-job throughput; the sharded-kernel-only figure is reported
+beside it (``kernel_only_patches_per_s``, ``allgather``).
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline      -- the batch kernel: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak
-  cpu_baseline  -- the oracle's restatement of the reference CPU path (same NumPy call) on this host
-  dense_frame   -- the dense-frame kernel (reference _zps.py:159-193) on the same frame, for context
+  roofline       -- the batch kernel: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak
+  cpu_baseline   -- the oracle's restatement of the reference CPU path (same NumPy call) on this host
+  north_star_4096, config2_batch, config2_dense, dense_frame, symmetry_pipeline -- the other single-GPU
+                    BASELINE configs, each with its own roofline object (N = 1)
+  host_api       -- NumPy in / NumPy out through ZPs.transform (PCIe-inclusive; never `value`)
+  multi_frame, sharded_maps -- configs[3] / configs[4] on N > 1 ranks
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,12 +34,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "motif-learn_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
-
-import numpy as np
-
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_VECTOR_PEAK_TF = 78.6     # public datasheet figure (not in the local guide); 62 TF measured,
-                               # tools/micro_sfma.hip, profiles/r01_micro_sfma.txt
 
 
 def parse():
@@ -43,18 +44,55 @@ def parse():
     ap.add_argument("--frame", type=int, default=2048, help="frame side (configs[1]: 2048)")
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--n-max", type=int, default=8)
-    ap.add_argument("--allgather-in-step", action="store_true",
-                    help="N>1: take `value` from the loop whose steps include the all-gather")
-    ap.add_argument("--no-allgather", action="store_true", help="N>1: skip the all-gather measurement")
+    ap.add_argument("--gather-chunks", type=int, default=4,
+                    help="N>1: chunks a rank's block is cut into (kernel of chunk c+1 overlaps the transfer of chunk c)")
+    ap.add_argument("--kernel-only-value", action="store_true",
+                    help="N>1: take `value` from the loop WITHOUT the all-gather (default: with it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-frame side measurement")
-    ap.add_argument("--no-maps", action="store_true", help="skip the configs[4] symmetry-map side measurement")
-    ap.add_argument("--with-4096", action="store_true",
-                    help="also time the north star's own size (all windows of a 4096^2 frame, 67.7 GB) -- opt-in: it "
-                         "launches the same kernel as the timed loop and would skew a rocprofv3 --stats average")
+    ap.add_argument("--no-maps", action="store_true", help="skip the configs[4] symmetry-map measurement")
+    ap.add_argument("--no-4096", action="store_true",
+                    help="skip the north star's own size (it launches the same kernel as the timed loop: use this "
+                         "flag under rocprofv3 --stats so that the average is the timed loop's)")
+    ap.add_argument("--no-config2", action="store_true", help="skip configs[2] (4096^2, 64-px, n_max 12)")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the NumPy-in / NumPy-out measurement")
+    ap.add_argument("--no-multi-frame", action="store_true", help="N>1: skip configs[3] (8 frames per rank)")
+    ap.add_argument("--only-timed-loop", action="store_true", help="skip every side measurement (profiling runs)")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------
+# self-launch: one child process per GPU, started before anything in this process touches the GPU
+# ---------------------------------------------------------------------------------------------------------
+def launch(args):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    code = 0
+    while procs:
+        for p in list(procs):
+            rc = p.poll()
+            if rc is None:
+                continue
+            procs.remove(p)
+            if rc != 0 and code == 0:
+                code = rc
+                for q in procs:                                           # one rank failed: stop the others
+                    q.terminate()
+        time.sleep(0.05)
+    return code
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baselines (oracle = checker and baseline only; never inside a timed GPU region)
+# ---------------------------------------------------------------------------------------------------------
 def cpu_baseline(z, frame, size):
     """Reference CPU path (np.dot of the flattened batch with the float64 basis, _zps.py:151-155)
     restated by the oracle, timed on a bounded sample of the same workload: the first 400k sliding
@@ -86,6 +124,7 @@ def cpu_baseline(z, frame, size):
 
 def cpu_dense_baseline(z, frame):
     """The reference's dense path (fftconvolve, _zps.py:159-193) on a 1024 x 1024 crop (~2.6 GB RSS)."""
+    import numpy as np
     from oracle import zernike_oracle as zo
     crop = np.ascontiguousarray(frame[:1024, :1024])
     t0 = time.perf_counter()
@@ -95,36 +134,69 @@ def cpu_dense_baseline(z, frame):
             "sample": f"oracle moments_frame_fft (scipy fftconvolve, single-threaded) on a 1024x1024 crop, {dt:.2f} s"}
 
 
-def main():
-    args = parse()
+def traffic_record(key):
+    """HBM bytes per launch from the PMC run recorded in profiles/traffic.json -- only if it was taken on the
+    kernel sources this run was built from."""
+    from mtflearn_amd import roofline as rl
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, "no profiles/traffic.json"
+    try:
+        rec = json.load(open(path)).get(key)
+    except Exception as exc:
+        return None, f"unreadable profiles/traffic.json: {exc}"
+    if not rec:
+        return None, f"no PMC record for {key}"
+    have = _kernel_source_hash()
+    if rec.get("kernel_source_sha") != have:
+        return None, (f"stale: {rec.get('source')} was taken at kernel_source_sha {rec.get('kernel_source_sha')} "
+                      f"(git {rec.get('git')}), sources are now {have}")
+    return rec["hbm_bytes_per_launch"], f"{rec.get('source')} @ git {rec.get('git')}, kernel_source_sha {have}"
+
+
+def _kernel_source_hash():
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "motif-learn_amd", "csrc", "*"))):
+        if path.endswith((".hip", ".h")):
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------
+def worker(args):
+    import numpy as np
     import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
     # Rehearsal knobs (a 1-GPU box cannot run RCCL between two ranks): ZK_BENCH_BACKEND=gloo with
-    # ZK_BENCH_ONE_DEVICE=1 puts every rank on device 0 and exercises the same control flow.
-    backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")
+    # ZK_BENCH_ONE_DEVICE=1 puts every rank on device 0 and runs the same drivers on the test-aid communicator.
+    backend = os.environ.get("ZK_BENCH_BACKEND", "rccl")
     if os.environ.get("ZK_BENCH_ONE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     os.environ["MTFLEARN_AMD_DEVICE"] = str(local_rank)
+
+    from mtflearn_amd import ZPs, _native, roofline as rl
+    from mtflearn_amd import distributed as D
+    from mtflearn_amd.synthetic import honeycomb_frame
+
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+        if backend == "gloo":
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+            comm = D.TorchComm()
         else:
-            dist.init_process_group(backend)
-
-    from mtflearn_amd import ZPs, _native
-    from mtflearn_amd.synthetic import honeycomb_frame
-    from mtflearn_amd.distributed import patch_moments_device, frame_moments_device
+            # ranks of one node meet through a file named after their common parent (the launcher) and port
+            path = f"/tmp/zk_comm_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.id"
+            comm = D.RcclComm(local_rank, rank, world, path=path)
 
     K, H = args.size, args.frame
     z = ZPs(n_max=args.n_max, size=K)
@@ -134,94 +206,89 @@ def main():
     f_dev = torch.from_numpy(frame).to(dev)
     patches = f_dev.unfold(0, K, 1).unfold(1, K, 1).reshape(-1, K, K).contiguous()
     n_local = patches.shape[0]
-    gather = world > 1 and not args.no_allgather
-    outs = [torch.empty((n_local, n_poly), dtype=torch.float64, device=dev) for _ in range(2 if gather else 1)]
-    fulls = [torch.empty((world * n_local, n_poly), dtype=torch.float64, device=dev) for _ in range(2)] if gather else []
+    n_total = world * n_local
+    start = rank * n_local
+    full = torch.empty((n_total, n_poly), dtype=torch.float64, device=dev)
+    mine = full[start:start + n_local]
     fast = plan.has_path(0, _native.ZK_F32, _native.PATH_SEPARABLE)
-
-    pending = [None, None]
-
-    def step(i, with_gather):
-        b = i & 1 if with_gather else 0
-        if with_gather and pending[b] is not None:
-            pending[b].wait()                                            # buffer pair b is free again
-        patch_moments_device(plan, patches, out=outs[b])
-        if with_gather:
-            pending[b] = dist.all_gather_into_tensor(fulls[b], outs[b], async_op=True)
-
-    def drain():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
         torch.cuda.synchronize()
 
-    def timed_loop(with_gather):
+    def step_kernel():
+        D.patch_moments_device(plan, patches, out=mine)
+
+    def step_gather():
+        D.sharded_patch_moments(plan, comm, patches, n_total, out=full, n_chunks=args.gather_chunks)
+
+    def timed_loop(step):
         """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks."""
-        for i in range(args.warmup):
-            step(i, with_gather)
-        drain()
+        for _ in range(args.warmup):
+            step()
         fence()
         plan.profile(True)
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i, with_gather)
-        drain()
+        for _ in range(args.steps):
+            step()
         fence()
         dt = time.perf_counter() - t0
         launches, kernel_ms = plan.profile_read()
         plan.profile(False)
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return t.item(), launches, kernel_ms
+        if comm is not None:
+            dt = comm.max_over_ranks(dt)
+            kernel_ms = comm.max_over_ranks(kernel_ms)
+        return dt, launches, kernel_ms
 
-    elapsed, launches, kernel_ms = timed_loop(False)
-    in_step = False
-    gathered_ok = allgather_ms = elapsed_gather = None
-    if gather:
-        elapsed_gather, l2, k2 = timed_loop(True)
-        last = (args.steps - 1) & 1
-        mine = fulls[last][rank * n_local:(rank + 1) * n_local]
-        ok = torch.tensor([int(torch.equal(mine, outs[last]))], device=dev)
-        # every rank's block must have arrived: the first entry of each block is finite and non-zero
-        heads = fulls[last][::n_local, 0]
-        ok &= int(bool(torch.isfinite(heads).all() and (heads != 0).all()))
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        gathered_ok = bool(ok.item())
+    el_kernel, l_kernel, ms_kernel = timed_loop(step_kernel)
+    gather = None
+    if world > 1:
+        el_gather, l_gather, ms_gather = timed_loop(step_gather)
+        # verification: my block is what my kernel wrote; every other block carries its owner's checksum
+        check = torch.empty((n_local, n_poly), dtype=torch.float64, device=dev)
+        D.patch_moments_device(plan, patches, out=check)
+        ok = bool(torch.equal(check, mine))
+        import struct
+        sums = [struct.unpack("d", b)[0] for b in comm.allgather_host(struct.pack("d", float(check.sum().item())))]
+        for r in range(world):
+            ok = ok and float(full[r * n_local:(r + 1) * n_local].sum().item()) == sums[r]
+        ok = comm.max_over_ranks(0.0 if ok else 1.0) == 0.0
+        del check
         fence()
         t1 = time.perf_counter()
         for _ in range(3):
-            dist.all_gather_into_tensor(fulls[0], outs[0])
+            comm.allgather_rows(full, 1, n_total, n_poly, n_local, 0, n_local, D._current_stream_ptr(full))
+            comm.join(D._current_stream_ptr(full))
         fence()
-        allgather_ms = (time.perf_counter() - t1) / 3 * 1e3
-        if args.allgather_in_step:
-            elapsed, launches, kernel_ms, in_step = elapsed_gather, l2, k2, True
+        alone_ms = comm.max_over_ranks((time.perf_counter() - t1) / 3 * 1e3)
+        gather = {"verified": ok, "ms_alone": alone_ms, "chunks": args.gather_chunks,
+                  "backend": "rccl (zk_allgather_rows in libzernike_hip.so)" if backend != "gloo" else "gloo (rehearsal)",
+                  "ms_per_step_with_allgather": el_gather / args.steps * 1e3,
+                  "value_with_allgather": n_total / (el_gather / args.steps),
+                  "ms_per_step_kernel_only": el_kernel / args.steps * 1e3,
+                  "value_kernel_only": n_total / (el_kernel / args.steps),
+                  "bytes_per_rank_out": n_local * n_poly * 8, "gathered_bytes": n_total * n_poly * 8,
+                  "GBps_received_per_rank": (world - 1) * n_local * n_poly * 8 / (alone_ms * 1e-3) / 1e9}
+
+    in_step = world > 1 and not args.kernel_only_value
+    elapsed, launches, kernel_ms = (el_gather, l_gather, ms_gather) if in_step else (el_kernel, l_kernel, ms_kernel)
+    side = {}
+    if world > 1 and not args.only_timed_loop:
+        side.update(multi_rank_sections(args, comm, rank, world, dev, plan, z))
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        if comm is not None:
+            comm.barrier()
+            comm.close()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * n_local / (elapsed / args.steps)
-    kern_ms = kernel_ms / max(launches, 1)
-    alg_bytes = n_local * (K * K * 4 + 8 * n_poly)                       # SURVEY 8d: K^2 s_in + 8 N_poly per patch
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath)).get(f"patches_{K}_{args.n_max}_{H}")
-            traffic = rec and rec.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    value = n_total / (elapsed / args.steps)
+    per_patch = rl.batch_bytes_per_patch(K, args.n_max, 4)
+    achieved = args.steps * n_local * per_patch / (kernel_ms * 1e-3) / 1e9      # all launches of the timed region
+    traffic, traffic_source = traffic_record(f"patches_{K}_{args.n_max}_{H}")
     result = {
         "metric": "patches/s (32x32, n_max=8) + achieved HBM GB/s vs roofline",
         "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -233,154 +300,275 @@ def main():
                    "patches_per_gpu": n_local, "patch_size": K, "n_max": args.n_max, "input_dtype": "f32",
                    "kernel": "zk_patch_sep_kernel (mirror-folded, row-separable, LDS-DMA staged)" if fast else "zk_generic_kernel",
                    "allgather_in_step": in_step,
-                   "parallelism": f"dp{world} (one frame's patch batch per GPU, no data-path collective; moment "
-                                  f"matrix reassembled by one RCCL all-gather, see 'allgather')"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel_ms": kern_ms, "launches": launches,
-                     "algorithmic_bytes_per_patch": K * K * 4 + 8 * n_poly},
-        "kernel_only_patches_per_s": world * n_local / (kern_ms * 1e-3),
+                   "parallelism": f"dp{world} (one frame's patch batch per GPU, no data-path collective"
+                                  + ("; every step ends with the all-gather of the moment matrix, chunked and "
+                                     "overlapped with the kernels)" if in_step else ")")},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": rl.HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / rl.HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel_ms": kernel_ms / args.steps, "launches": launches,
+                     "algorithmic_bytes_per_patch": per_patch, "patches_per_step": n_local},
+        "kernel_only_patches_per_s": n_total / (ms_kernel / args.steps * 1e-3),
     }
-    if allgather_ms is not None:
-        result["allgather"] = {"ms_alone": allgather_ms, "verified": gathered_ok,
-                               "ms_per_step_with_allgather_in_step": elapsed_gather / args.steps * 1e3,
-                               "value_with_allgather_in_step": world * n_local / (elapsed_gather / args.steps),
-                               "bytes_per_rank_out": n_local * n_poly * 8,
-                               "gathered_bytes": world * n_local * n_poly * 8}
+    if gather is not None:
+        result["allgather"] = gather
+    result.update(side)
 
-    # ---- dense-frame kernels on the same frame (side measurement, not `value`) -----------------------
-    if not args.no_dense:
-        out_f = frame_moments_device(plan, f_dev)
-        torch.cuda.synchronize()
-        npx, disk = H * H, plan.disk_pixels
-        # f64 operations the separable kernel executes per position (zk_sep.h): per quadrant disk pixel
-        # 8 adds + 2(n_max+1) FMAs, per disk row pair N_poly FMAs, one class-blocked T product
-        quad_px = int(np.count_nonzero(z.polynomials[0][:(K + 1) // 2, :(K + 1) // 2]))
-        row_pairs = int(np.any(z.polynomials[0][:(K + 1) // 2] != 0, axis=1).sum())
-        cls = [sum(1 for a in range(args.n_max + 1) for b in range(args.n_max + 1 - a) if (a % 2, b % 2) == pq)
-               for pq in ((0, 0), (1, 0), (0, 1), (1, 1))]
-        # (T is stored packed: entry (j, (a,b)) exists only for a + b <= n_j)
-        t_terms = 0
-        for pq, m_sel in (((0, 0), lambda m: m >= 0 and m % 2 == 0), ((1, 0), lambda m: m >= 0 and m % 2 == 1),
-                          ((0, 1), lambda m: m < 0 and m % 2 == 1), ((1, 1), lambda m: m < 0 and m % 2 == 0)):
-            degs = [a + b for a in range(args.n_max + 1) for b in range(args.n_max + 1 - a) if (a % 2, b % 2) == pq]
-            zns = [n for n in range(args.n_max + 1) for m in range(-n, n + 1, 2) if m_sel(m)]
-            t_terms += sum(1 for n in zns for d in degs if d <= n)
-        sep_flops = quad_px * (8 + 4 * (args.n_max + 1)) + 2 * row_pairs * n_poly + 2 * t_terms
-        # strip kernel (zk_sep_strip.hip; n_max <= 8, windows <= 65 px): per PAIR of outputs every frame row is swept
-        # once from the centre to the wider of the two inner limits (2 adds + (n_max+1) FMAs per column pair), every
-        # disk row of either output costs N_poly FMAs, and there are two T products
-        strip = args.n_max <= 8 and (K + 7) * (K + 63) * 8 <= 80 * 1024 and not os.environ.get("ZK_NO_STRIP")
-        if strip:
-            Qh = (K + 1) // 2
-            mask = z.polynomials[0] != 0
-            cmin = [int(np.argmax(mask[r, :Qh])) if mask[r, :Qh].any() else Qh for r in range(K)]
-            sweep_cols = sum(Qh - min(cmin[fr] if fr < K else Qh, cmin[fr - 1] if fr > 0 else Qh) for fr in range(K + 1))
-            disk_rows = sum(1 for c in cmin if c < Qh)
-            sep_flops = (sweep_cols * (2 + 2 * (args.n_max + 1)) + 2 * disk_rows * 2 * n_poly + 2 * 2 * t_terms) / 2
-        dense = {"positions": npx, "bound": "fp64-valu", "fp64_vector_peak_TFLOPs": FP64_VECTOR_PEAK_TF,
-                 "kernels": {}}
-        for path in (_native.PATH_SEPARABLE, _native.PATH_FOLDED):
-            if not plan.has_path(1, _native.ZK_F32, path):
-                continue
-            plan.set_path(path)
-            frame_moments_device(plan, f_dev, out=out_f)
-            torch.cuda.synchronize()
-            plan.profile(True)
-            for _ in range(5):
-                frame_moments_device(plan, f_dev, out=out_f)
-            torch.cuda.synchronize()
-            ln, ms = plan.profile_read()
-            plan.profile(False)
-            fms = ms / ln
-            dense["kernels"][_native.PATH_NAMES[path]] = {
-                "patches_per_s": npx / (fms * 1e-3), "kernel_ms": fms,
-                "hbm_GBps_algorithmic": npx * (4 + 8 * n_poly) / (fms * 1e-3) / 1e9,
-                "hbm_frac": npx * (4 + 8 * n_poly) / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "fp64_TFLOPs_direct_equiv": npx * 2.0 * disk * n_poly / (fms * 1e-3) / 1e12}
-            if path == _native.PATH_SEPARABLE:
-                ex = npx * sep_flops / (fms * 1e-3) / 1e12
-                dense["kernels"]["separable"].update({"fp64_TFLOPs_executed": ex,
-                                                      "fp64_frac_of_peak": ex / FP64_VECTOR_PEAK_TF,
-                                                      "kernel": "zk_frame_strip_kernel" if strip else "zk_frame_sep_kernel",
-                                                      "fp64_flops_per_position": sep_flops})
-        plan.set_path(_native.PATH_AUTO)
-        result["dense_frame"] = dense
-        del out_f
-
-    # ---- configs[4]: full symmetry-map pipeline, 4096^2, n_max = 10, fused on device (side measurement) ---
-    if not args.no_maps and world == 1:
-        from mtflearn_amd.distributed import frame_maps_device
-        del patches, outs
+    if world == 1 and not args.only_timed_loop:
+        del patches, full, mine
         torch.cuda.empty_cache()
+        single_gpu_sections(args, result, dev, plan, z, f_dev, frame)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(z, frame, K)
+            result["cpu_baseline_dense"] = cpu_dense_baseline(z, frame)
+            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+    print(json.dumps(result))
+    sys.stdout.flush()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# configs[3] / configs[4] at N > 1 (every rank takes part; rank 0 reports)
+# ---------------------------------------------------------------------------------------------------------
+def multi_rank_sections(args, comm, rank, world, dev, plan, z):
+    import numpy as np
+    import torch
+    from mtflearn_amd import ZPs, distributed as D, roofline as rl
+    from mtflearn_amd.synthetic import honeycomb_frame
+    out = {}
+    K = args.size
+    stream_of = D._current_stream_ptr
+
+    def fence():
+        torch.cuda.synchronize()
+        comm.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, reps):
+        fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        fence()
+        return comm.max_over_ranks((time.perf_counter() - t0) / reps)
+
+    if not args.no_multi_frame:
+        # configs[3]: 8 frames of 2048^2 per rank, moments of all 8 x world frames reassembled on every rank
+        per_rank, Hf = 8, args.frame
+        n_frames = per_rank * world
+        frames = torch.stack([torch.from_numpy(honeycomb_frame(Hf, seed=1000 + rank * per_rank + i)) for i in range(per_rank)]).to(dev)
+        full = torch.empty((n_frames, plan.n_poly, Hf, Hf), dtype=torch.float64, device=dev)
+        sec = timed(lambda: D.sharded_frames_moments(plan, comm, frames, n_frames, out=full), 2)
+        sec_k = timed(lambda: [D.frame_moments_device(plan, frames[i], out=full[rank * per_rank + i]) for i in range(per_rank)], 2)
+        heads = full[:, 0, Hf // 2, Hf // 2]
+        ok = bool(torch.isfinite(heads).all() and (heads != 0).all())
+        out["multi_frame"] = {
+            "workload": f"configs[3]: {n_frames} synthetic {Hf}x{Hf} frames, {per_rank} per GPU, dense {K}-px moments, "
+                        f"(F, {plan.n_poly}, H, W) reassembled on every rank (frame i gathered while frame i+1 is computed)",
+            "positions_per_s_with_allgather": n_frames * Hf * Hf / sec, "s_per_pass_with_allgather": sec,
+            "positions_per_s_kernels_only": n_frames * Hf * Hf / sec_k, "s_per_pass_kernels_only": sec_k,
+            "gathered_bytes": full.numel() * 8, "all_blocks_arrived": comm.max_over_ranks(0.0 if ok else 1.0) == 0.0}
+        del frames, full
+        torch.cuda.empty_cache()
+    if not args.no_maps:
+        # configs[4]: one 4096^2 frame, n_max 10, row bands -> fused maps -> the 41 map planes gathered
         z10 = ZPs(n_max=10, size=K)
         plan10 = z10._device_plan()
         big = torch.from_numpy(honeycomb_frame(4096, seed=1)).to(dev)
         theta = np.linspace(0, 2 * np.pi, 360, endpoint=False)
-        n_c = sum(n // 2 + 1 for n in range(11))
-        if plan10.has_path(1, _native.ZK_F32, _native.PATH_SEPARABLE):
-            frame_maps_device(plan10, big, n_c, theta=theta)
-            torch.cuda.synchronize()
-            plan10.profile(True)
-            for _ in range(3):
-                frame_maps_device(plan10, big, n_c, theta=theta)
-            torch.cuda.synchronize()
-            ln, ms = plan10.profile_read()
-            mom = frame_moments_device(plan10, big)
-            torch.cuda.synchronize()
-            for _ in range(3):
-                frame_moments_device(plan10, big, out=mom)
-            torch.cuda.synchronize()
-            ln2, ms2 = plan10.profile_read()
-            plan10.profile(False)
-            result["symmetry_pipeline"] = {
-                "workload": "configs[4]: 4096x4096 frame, 32-px, n_max=10 -> rot_maps[2,3,4,6] + 36 |Z_nm| planes + "
-                            "mirror_map(360 angles), fused in one kernel",
-                "fused_kernel_ms": ms / ln, "positions_per_s": 4096 * 4096 / (ms / ln * 1e-3),
-                "moments_only_kernel_ms": ms2 / ln2,
-                "out_bytes_fused": 41 * 4096 * 4096 * 8, "out_bytes_moments": 66 * 4096 * 4096 * 8}
-            del mom
-        del big
-
-    # ---- north star's own size: all dense 32-px windows of a 4096^2 frame as one batch (side measurement) --
-    if world == 1 and args.with_4096 and K == 32:
-        try:
-            del patches, outs                                            # (already gone if the maps section ran)
-        except NameError:
-            pass
+        n_c = rl.n_complex(10)
+        res = {}
+        sec = timed(lambda: res.__setitem__("m", D.sharded_frame_maps(plan10, comm, big, n_c, theta=theta,
+                                                                       n_chunks=args.gather_chunks)), 3)
+        rot, ab, mir = res["m"]
+        ok = bool(torch.isfinite(mir[64:-64:512, 64:-64:512]).all())
+        out["sharded_maps"] = {
+            "workload": "configs[4]: 4096x4096 frame, 32-px, n_max=10 -> rot_maps[2,3,4,6] + 36 |Z_nm| planes + mirror_map(360), "
+                        f"row bands over {world} GPUs, 41 map planes gathered on every rank",
+            "positions_per_s": 4096 * 4096 / sec, "s_per_pass": sec, "gathered_bytes": 41 * 4096 * 4096 * 8,
+            "all_bands_arrived": comm.max_over_ranks(0.0 if ok else 1.0) == 0.0}
+        del big, rot, ab, mir, res
         torch.cuda.empty_cache()
-        free_b, _tot = torch.cuda.mem_get_info()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the other single-GPU BASELINE configs, each with its own roofline (N = 1, rank 0)
+# ---------------------------------------------------------------------------------------------------------
+def _profiled(plan, fn, reps):
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    plan.profile(True)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    launches, ms = plan.profile_read()
+    plan.profile(False)
+    return ms / reps, launches // reps
+
+
+def _hbm_roofline(bytes_per_pass, ms):
+    from mtflearn_amd import roofline as rl
+    a = bytes_per_pass / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": a, "peak": rl.HBM_PEAK_GBS, "unit": "GB/s", "frac": a / rl.HBM_PEAK_GBS}
+
+
+def _fp64_roofline(flops_per_pass, bytes_per_pass, ms):
+    from mtflearn_amd import roofline as rl
+    t = flops_per_pass / (ms * 1e-3) / 1e12
+    return {"bound": "fp64-valu", "achieved": t, "peak": rl.FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s (executed f64)",
+            "frac": t / rl.FP64_VECTOR_PEAK_TF, "hbm_GBps_algorithmic": bytes_per_pass / (ms * 1e-3) / 1e9,
+            "hbm_frac": bytes_per_pass / (ms * 1e-3) / 1e9 / rl.HBM_PEAK_GBS}
+
+
+def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
+    import numpy as np
+    import torch
+    from mtflearn_amd import ZPs, _native, distributed as D, roofline as rl
+    from mtflearn_amd.synthetic import honeycomb_frame
+    K, H, n_max = args.size, args.frame, args.n_max
+    n_poly = len(z.n)
+
+    # ---- configs[1] in dense form: the dense-frame kernels on the same frame -------------------------------
+    if not args.no_dense:
+        out_f = D.frame_moments_device(plan, f_dev)
+        npx = H * H
+        strip = n_max <= 8 and (K + 7) * (K + 63) * 8 <= 80 * 1024 and not os.environ.get("ZK_NO_STRIP")
+        flops = rl.strip_flops_per_unit(z.polynomials[0], n_max) if strip else rl.sep_flops_per_unit(z.polynomials[0], n_max)
+        dense = {"positions": npx, "kernels": {}}
+        for path in (_native.PATH_SEPARABLE, _native.PATH_FOLDED):
+            if not plan.has_path(1, _native.ZK_F32, path):
+                continue
+            plan.set_path(path)
+            ms, _ = _profiled(plan, lambda: D.frame_moments_device(plan, f_dev, out=out_f), 5)
+            entry = {"patches_per_s": npx / (ms * 1e-3), "kernel_ms": ms}
+            if path == _native.PATH_SEPARABLE:
+                entry["kernel"] = "zk_frame_strip_kernel" if strip else "zk_frame_sep_kernel"
+                entry["fp64_flops_per_position"] = flops
+                entry["roofline"] = _fp64_roofline(npx * flops, npx * rl.dense_bytes_per_position(n_max), ms)
+            else:
+                entry["kernel"] = "zk_frame_fold_kernel"
+                entry["roofline"] = _fp64_roofline(npx * (rl.direct_flops_per_unit(z.polynomials[0], n_max) / 4 + 8 * K * K / 4),
+                                                   npx * rl.dense_bytes_per_position(n_max), ms)
+            dense["kernels"][_native.PATH_NAMES[path]] = entry
+        plan.set_path(_native.PATH_AUTO)
+        result["dense_frame"] = dense
+        del out_f
+        torch.cuda.empty_cache()
+
+    # ---- north star's own size: all dense 32-px windows of a 4096^2 frame as one batch ----------------------
+    if not args.no_4096 and K == 32:
         n4 = (4096 - K + 1) ** 2
-        need = n4 * (K * K * 4 + 8 * n_poly) + 4096 * 4096 * 4
-        if free_b > need * 1.1:
+        need = n4 * rl.batch_bytes_per_patch(K, n_max) + 4096 * 4096 * 4
+        if torch.cuda.mem_get_info()[0] > need * 1.1:
             f4 = torch.from_numpy(honeycomb_frame(4096, seed=2)).to(dev)
             p4 = f4.unfold(0, K, 1).unfold(1, K, 1).reshape(-1, K, K).contiguous()
             o4 = torch.empty((n4, n_poly), dtype=torch.float64, device=dev)
-            patch_moments_device(plan, p4, out=o4)
-            torch.cuda.synchronize()
-            plan.profile(True)
-            for _ in range(5):
-                patch_moments_device(plan, p4, out=o4)
-            torch.cuda.synchronize()
-            ln4, ms4 = plan.profile_read()
-            plan.profile(False)
-            k4 = ms4 / ln4
+            ms, _ = _profiled(plan, lambda: D.patch_moments_device(plan, p4, out=o4), 5)
             result["north_star_4096"] = {
-                "workload": f"all {n4} dense {K}-px windows of a 4096x4096 frame as one float32 batch ({n4 * K * K * 4 / 1e9:.1f} GB), n_max={args.n_max}",
-                "kernel_ms": k4, "patches_per_s": n4 / (k4 * 1e-3),
-                "hbm_GBps_algorithmic": n4 * (K * K * 4 + 8 * n_poly) / (k4 * 1e-3) / 1e9,
-                "hbm_frac": n4 * (K * K * 4 + 8 * n_poly) / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                "workload": f"north_star: all {n4} dense {K}-px windows of a 4096x4096 frame as one float32 batch "
+                            f"({n4 * K * K * 4 / 1e9:.1f} GB), n_max={n_max}",
+                "kernel_ms": ms, "patches_per_s": n4 / (ms * 1e-3),
+                "roofline": _hbm_roofline(n4 * rl.batch_bytes_per_patch(K, n_max), ms)}
             del p4, o4, f4
             torch.cuda.empty_cache()
 
-    if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(z, frame, K)
-        result["cpu_baseline_dense"] = cpu_dense_baseline(z, frame)
-        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
-    print(json.dumps(result))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    # ---- configs[2]: 4096^2 frame, 64-px windows, n_max 12 -- batch form (HBM) and dense form (FP64) --------
+    if not args.no_config2:
+        z12 = ZPs(n_max=12, size=64)
+        plan12 = z12._device_plan()
+        f2 = torch.from_numpy(honeycomb_frame(4096, seed=3)).to(dev)
+        rows = 496                                                       # 496 x 4033 = 2.0 M windows = 32.8 GB
+        p2 = f2[:rows + 63].unfold(0, 64, 1).unfold(1, 64, 1).reshape(-1, 64, 64).contiguous()
+        o2 = torch.empty((p2.shape[0], 91), dtype=torch.float64, device=dev)
+        ms, _ = _profiled(plan12, lambda: D.patch_moments_device(plan12, p2, out=o2), 5)
+        result["config2_batch"] = {
+            "workload": f"configs[2] in batch form: {p2.shape[0]} dense 64-px windows (the first {rows} window rows of a "
+                        f"4096x4096 frame; all 16.3 M would be 266 GB) as one float32 batch, n_max=12 (91 moments)",
+            "kernel_ms": ms, "patches_per_s": p2.shape[0] / (ms * 1e-3),
+            "roofline": _hbm_roofline(p2.shape[0] * rl.batch_bytes_per_patch(64, 12), ms)}
+        del p2, o2
+        torch.cuda.empty_cache()
+        od = torch.empty((91, 4096, 4096), dtype=torch.float64, device=dev)
+        ms, _ = _profiled(plan12, lambda: D.frame_moments_device(plan12, f2, out=od), 3)
+        flops = rl.sep_flops_per_unit(z12.polynomials[0], 12)
+        result["config2_dense"] = {
+            "workload": "configs[2]: 4096x4096 frame, every 64-px window (zero-padded 'same' positions), n_max=12 -> (91, 4096, 4096) float64",
+            "kernel": "zk_frame_sep_kernel<12>", "kernel_ms": ms, "positions_per_s": 4096 * 4096 / (ms * 1e-3),
+            "fp64_flops_per_position": flops,
+            "roofline": _fp64_roofline(4096 * 4096 * flops, 4096 * 4096 * rl.dense_bytes_per_position(12), ms)}
+        del od, f2, plan12, z12
+        torch.cuda.empty_cache()
+
+    # ---- configs[4]: full symmetry-map pipeline, 4096^2, n_max = 10, fused on device ---------------------------
+    if not args.no_maps:
+        z10 = ZPs(n_max=10, size=K)
+        plan10 = z10._device_plan()
+        big = torch.from_numpy(honeycomb_frame(4096, seed=1)).to(dev)
+        theta = np.linspace(0, 2 * np.pi, 360, endpoint=False)
+        n_c = rl.n_complex(10)
+        if plan10.supports(_native.OP_MAPS, _native.ZK_F32):
+            rot = torch.empty((4, 4096, 4096), dtype=torch.float64, device=dev)
+            ab = torch.empty((n_c, 4096, 4096), dtype=torch.float64, device=dev)
+            mir = torch.empty((4096, 4096), dtype=torch.float64, device=dev)
+            ms, _ = _profiled(plan10, lambda: D.frame_maps_device(plan10, big, n_c, theta=theta, full=(rot, ab, mir)), 3)
+            del rot, ab, mir
+            mom = torch.empty((66, 4096, 4096), dtype=torch.float64, device=dev)
+            ms2, _ = _profiled(plan10, lambda: D.frame_moments_device(plan10, big, out=mom), 3)
+            del mom
+            flops = rl.sep_flops_per_unit(z10.polynomials[0], 10) + rl.maps_tail_flops(10, 4, 360)
+            result["symmetry_pipeline"] = {
+                "workload": "configs[4]: 4096x4096 frame, 32-px, n_max=10 -> rot_maps[2,3,4,6] + 36 |Z_nm| planes + "
+                            "mirror_map(360 angles), fused in one kernel",
+                "kernel": "zk_frame_maps_kernel<10>", "fused_kernel_ms": ms, "positions_per_s": 4096 * 4096 / (ms * 1e-3),
+                "moments_only_kernel_ms": ms2, "fp64_flops_per_position": flops,
+                "out_bytes_fused": 41 * 4096 * 4096 * 8, "out_bytes_moments": 66 * 4096 * 4096 * 8,
+                "roofline": _fp64_roofline(4096 * 4096 * flops, 4096 * 4096 * rl.dense_bytes_per_position(10, planes=41), ms)}
+        del big
+        torch.cuda.empty_cache()
+
+    # ---- NumPy in / NumPy out through the drop-in call (PCIe-inclusive; never `value`) ------------------------
+    if not args.no_host_api:
+        from mtflearn_amd.synthetic import sliding_patches
+        n_side = H - K + 1
+        rows = -(-500000 // n_side)
+        batch = sliding_patches(frame, K, rows=range(rows))[:500000]
+        z.transform(batch[:4096])
+        best = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            zm = z.transform(batch)
+            best = min(best, time.perf_counter() - t0)
+        del zm
+        big = honeycomb_frame(4096, seed=2)
+        z.transform(big)                                                 # first call: allocates the pinned result block
+        bestf = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter()
+            zm = z.transform(big)
+            bestf = min(bestf, time.perf_counter() - t0)
+        del zm
+        z.release()
+        _native.pinned.trim()
+        in_b, out_b = batch.nbytes, batch.shape[0] * n_poly * 8
+        result["host_api"] = {
+            "patches_per_s": batch.shape[0] / best, "batch": f"{batch.shape[0]} float32 {K}-px patches (pageable NumPy array) "
+                                                             f"-> ZPs.transform -> (N, {n_poly}) float64",
+            "batch_s": best, "batch_pcie_GBps": (in_b + out_b) / best / 1e9,
+            "pcie_bound_patches_per_s": 63e9 / (K * K * 4),
+            "frame_4096_s": bestf, "frame": f"4096x4096 float32 frame -> ZPs.transform -> ({n_poly}, 4096, 4096) float64 "
+                                            f"({n_poly * 4096 * 4096 * 8 / 1e9:.1f} GB, page-locked result from the pool)",
+            "frame_pcie_GBps": n_poly * 4096 * 4096 * 8 / bestf / 1e9}
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch(args))
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -19,7 +19,8 @@
  *   - the caller owns every host buffer; inputs are read-only, outputs are C-contiguous
  *     float64; no pointer is retained after the call returns.  Device memory owned by the
  *     library lives inside the plan and is released by zk_plan_destroy().
- *   - a plan is bound to one device and is not thread-safe (one stream per plan).
+ *   - a plan is bound to one device and is not thread-safe (one stream per plan).  Every entry point
+ *     leaves the calling thread's current HIP device as it found it.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails.
  */
 #ifndef ZERNIKE_HIP_H
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZK_ABI_VERSION 1
+#define ZK_ABI_VERSION 2
 
 /* element type of the image / patch operand */
 #define ZK_F32 0
@@ -41,6 +42,7 @@ extern "C" {
 #define ZK_E_BADARG   (-10001)
 #define ZK_E_NODEVICE (-10002)
 #define ZK_E_NOMEM    (-10003)
+#define ZK_E_COMM     (-10004)  /* RCCL unavailable, rendezvous failed or a collective returned an error */
 
 /* kernel selection, for tests and A/B measurements (default ZK_PATH_AUTO = best available) */
 #define ZK_PATH_AUTO      0
@@ -116,6 +118,15 @@ int zk_transform_frame_dev(zk_plan* plan, const void* image_dev, int dtype, int6
                            void* hip_stream);
 
 /*
+ * Row band written IN PLACE into a larger array: as zk_transform_frame_dev, but plane j of the band starts
+ * at out_dev + j * plane_stride (doubles).  With out_dev = full + row0 * W and plane_stride = H * W the
+ * band lands inside the full (n_poly, H, W) array -- the layout zk_allgather_rows reassembles without a copy.
+ */
+int zk_transform_frame_dev_strided(zk_plan* plan, const void* image_dev, int dtype, int64_t height,
+                                   int64_t width, int64_t row0, int64_t n_rows, double* out_dev,
+                                   int64_t plane_stride, void* hip_stream);
+
+/*
  * Moments of the size x size windows at given positions of a frame: the device form of "cut patches at
  * key points, then transform the batch" (reference features/_keypoint.py:60-78 + _zps.py:146-157)
  * without materialising the (N, size, size) batch.
@@ -153,6 +164,14 @@ int zk_frame_maps_dev(zk_plan* plan, const void* image_dev, int dtype, int64_t h
                       const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta, int n_theta,
                       double* rot_dev, double* abs_dev, double* mirror_dev, void* hip_stream);
 
+/* As zk_frame_maps_dev with every output plane `plane_stride` doubles apart (see zk_transform_frame_dev_strided);
+ * rot_dev / abs_dev / mirror_dev point at the first row of the band inside their full arrays. */
+int zk_frame_maps_dev_strided(zk_plan* plan, const void* image_dev, int dtype, int64_t height, int64_t width,
+                              int64_t row0, int64_t n_rows, const int32_t* folds, int n_folds,
+                              const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta,
+                              int n_theta, double* rot_dev, double* abs_dev, double* mirror_dev,
+                              int64_t plane_stride, void* hip_stream);
+
 /*
  * Kernel timing with HIP events on the stream the kernels are launched on.
  * zk_plan_profile(plan, 1) brackets every subsequent kernel launch with an event pair;
@@ -161,6 +180,75 @@ int zk_frame_maps_dev(zk_plan* plan, const void* image_dev, int dtype, int64_t h
  */
 int zk_plan_profile(zk_plan* plan, int enable);
 int zk_plan_profile_read(zk_plan* plan, int64_t* launches, double* total_ms);
+
+/*
+ * Host staging of the host-buffer entry points (zk_transform_patches / _frame / _points, zk_frame_maps): the
+ * job is cut into chunks of at most `chunk_bytes` of input + output (default 256 MiB, ZK_HOST_CHUNK_MB in the
+ * environment), each chunk goes host -> pinned ring -> device -> kernel -> pinned ring -> host with the
+ * three stages of consecutive chunks overlapping on three streams; the device footprint is bounded by the
+ * ring, whatever the job size.  zk_plan_release_staging frees the ring and every grown staging buffer
+ * (they are re-created on demand).
+ */
+int zk_plan_set_host_chunk(zk_plan* plan, int64_t chunk_bytes);
+int zk_plan_release_staging(zk_plan* plan);
+/* Page-locked host memory (hipHostMalloc, portable): arrays in it move over PCIe by DMA at link speed and
+ * without blocking the calling thread; free with zk_host_free. */
+int zk_host_alloc(int64_t bytes, void** out_host);
+int zk_host_free(void* host);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, units sharded with no data-path collective, ONE exchange step that
+ * reassembles the result on every rank (north_star "a single RCCL all-gather over xGMI").
+ * The reference has no counterpart (single-process NumPy).  RCCL is loaded on first use (dlopen of the
+ * librccl.so.1 already in the process, else the one next to the HIP runtime in use, else the system's), so
+ * the library itself has no link-time dependency on it.
+ *
+ * A communicator owns one RCCL communicator and one HIP stream of its own.  Collectives are ORDERED AFTER
+ * everything enqueued so far on the `hip_stream` argument (the producer's stream) but RUN on the
+ * communicator's stream, so kernels enqueued later on `hip_stream` overlap with the transfer;
+ * zk_comm_join(comm, hip_stream) makes `hip_stream` wait for every collective issued so far.  Nothing here
+ * synchronises the host except zk_comm_allgather_host and the init / destroy calls.
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct zk_comm zk_comm;
+#define ZK_COMM_ID_BYTES 128
+
+/* Rendezvous.  Any of the three: (a) the caller moves the 128-byte id from rank 0 to the others itself;
+ * (b) ranks of one node meet through a file: rank 0 writes the id to `path` (atomically), the others poll it,
+ * rank 0 removes it once everyone has joined; (c) rank 0 listens on host:port and hands the id to each peer. */
+int zk_comm_unique_id(void* id_out /* ZK_COMM_ID_BYTES */);
+int zk_comm_init_rank(int device, int rank, int world, const void* id, zk_comm** out);
+int zk_comm_init_file(int device, int rank, int world, const char* path, double timeout_s, zk_comm** out);
+int zk_comm_init_tcp(int device, int rank, int world, const char* host, int port, double timeout_s, zk_comm** out);
+int zk_comm_destroy(zk_comm* comm);
+int zk_comm_rank(const zk_comm* comm);
+int zk_comm_world(const zk_comm* comm);
+
+/*
+ * In-place all-gather of row blocks.  `full_dev` is the same-shaped (n_planes, H, W) float64 array on every
+ * rank; rank r owns rows [r * rows_per_rank, min((r + 1) * rows_per_rank, H)) of every plane (the blocks of
+ * shard_bounds: equal, the tail ranks possibly short or empty).  On entry each rank holds valid data in rows
+ * [row_off, row_off + n_rows) of ITS block (clipped to the block); on completion those rows of EVERY block are
+ * valid on every rank.  row_off = 0, n_rows = rows_per_rank gathers whole blocks; smaller windows are the
+ * chunks of a pipelined gather (kernel of chunk c+1 overlapping the transfer of chunk c).
+ *   moment matrix of a patch batch (N, n_poly):      n_planes = 1, H = N, W = n_poly
+ *   dense moments / symmetry maps (planes, H, W):    rows of the frame
+ *   a batch of frames (F, n_poly, H, W):             n_planes = 1, H = F, W = n_poly * H * W
+ * Whole equal blocks of a single plane go through ncclAllGather (in place); everything else is one grouped
+ * ncclSend / ncclRecv per peer and plane -- on the fully connected xGMI mesh that is the direct exchange
+ * (every link carries one block, no ring forwarding).  ZK_COMM_ALGO=p2p|allgather|bcast in the environment
+ * forces one form (bcast: one grouped ncclBroadcast per owner).
+ */
+int zk_allgather_rows(zk_comm* comm, double* full_dev, int64_t n_planes, int64_t height, int64_t width,
+                      int64_t rows_per_rank, int64_t row_off, int64_t n_rows, void* hip_stream);
+int zk_comm_join(zk_comm* comm, void* hip_stream);
+/* Blocking all-gather of a few host bytes per rank (timings, checksums; doubles as a barrier). */
+int zk_comm_allgather_host(zk_comm* comm, const void* send_host, void* recv_host, int64_t bytes_per_rank);
+
+/* Device memory for callers that have no allocator of their own (a NumPy / C user of the *_dev entry points). */
+int zk_device_malloc(int device, int64_t bytes, void** out_dev);
+int zk_device_free(int device, void* dev);
+int zk_device_copy(int device, void* dst, const void* src, int64_t bytes, int kind /* 1 H2D, 2 D2H, 3 D2D */);
+int zk_device_synchronize(int device);
 
 #ifdef __cplusplus
 }

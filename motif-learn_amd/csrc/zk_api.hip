@@ -69,7 +69,7 @@ extern "C" int zk_plan_profile(zk_plan* p, int enable) {
 
 extern "C" int zk_plan_profile_read(zk_plan* p, int64_t* launches, double* total_ms) {
   if (!p) return zk_fail(ZK_E_BADARG, "null plan");
-  ZK_HIP(hipSetDevice(p->device));
+  ZK_ON_PLAN_DEVICE(p);
   for (size_t k = 0; k + 1 < p->ev_used; k += 2) {
     ZK_HIP(hipEventSynchronize(p->ev_pool[k + 1]));
     float ms = 0.f;
@@ -119,15 +119,14 @@ static int build_generic_tables(zk_plan* p, const double* basis) {
 
 extern "C" void zk_plan_destroy(zk_plan* p) {
   if (!p) return;
-  (void)hipSetDevice(p->device);
+  zk_device_scope scope(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   zk_fold_free(p);
   zk_sep_free(p);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   if (p->d_pix) (void)hipFree(p->d_pix);
   if (p->d_gen_tab) (void)hipFree(p->d_gen_tab);
-  if (p->d_in) (void)hipFree(p->d_in);
-  if (p->d_out) (void)hipFree(p->d_out);
+  zk_host_release(p);
   if (p->d_scratch) (void)hipFree(p->d_scratch);
   if (p->d_gather) (void)hipFree(p->d_gather);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -153,7 +152,8 @@ extern "C" int zk_plan_create(int size, int n_poly, const int32_t* n, const int3
   p->n.assign(n, n + n_poly);
   p->m.assign(m, m + n_poly);
   int rc = 0;
-  hipError_t e = hipSetDevice(device);
+  zk_device_scope scope(device);
+  hipError_t e = scope.err;
   if (e != hipSuccess) rc = zk_hip_fail(e, "hipSetDevice");
   if (!rc) {
     e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
@@ -238,7 +238,7 @@ extern "C" int zk_transform_patches_dev(zk_plan* p, const void* patches, int dty
   if (n_patches < 0) return zk_fail(ZK_E_BADARG, "negative patch count");
   if (n_patches == 0) return 0;
   if (!patches || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
-  ZK_HIP(hipSetDevice(p->device));
+  ZK_ON_PLAN_DEVICE(p);
   hipStream_t s = (hipStream_t)hip_stream;  // exactly the caller's stream; NULL is HIP's default stream
   const int path = resolve_path(p, 0, dtype, n_patches);
   if (path < 0) return zk_fail(ZK_E_BADARG, "the forced kernel path is not available for this plan / dtype");
@@ -256,7 +256,7 @@ extern "C" int zk_transform_frame_dev(zk_plan* p, const void* image, int dtype, 
   if (row0 < 0 || n_rows < 0 || row0 + n_rows > H) return zk_fail(ZK_E_BADARG, "row band outside the frame");
   if (n_rows == 0) return 0;
   if (!image || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
-  ZK_HIP(hipSetDevice(p->device));
+  ZK_ON_PLAN_DEVICE(p);
   hipStream_t s = (hipStream_t)hip_stream;  // exactly the caller's stream; NULL is HIP's default stream
   const int path = resolve_path(p, 1, dtype);
   if (path < 0) return zk_fail(ZK_E_BADARG, "the forced kernel path is not available for this plan / dtype");
@@ -269,61 +269,21 @@ extern "C" int zk_transform_frame_dev(zk_plan* p, const void* image, int dtype, 
   return zk_launch_generic_frame(p, image, dtype, H, W, row0, n_rows, out, s);
 }
 
-static int ensure(void** buf, size_t* have, size_t need) {
-  if (*have >= need) return 0;
-  if (*buf) {
-    ZK_HIP(hipFree(*buf));
-    *buf = nullptr;
-    *have = 0;
-  }
-  ZK_HIP(hipMalloc(buf, need));
-  *have = need;
-  return 0;
-}
-
-extern "C" int zk_transform_patches(zk_plan* p, const void* patches_host, int dtype, int64_t n_patches,
-                                    double* out_host) {
+extern "C" int zk_transform_frame_dev_strided(zk_plan* p, const void* image, int dtype, int64_t H, int64_t W,
+                                              int64_t row0, int64_t n_rows, double* out, int64_t plane_stride,
+                                              void* hip_stream) {
   if (!p) return zk_fail(ZK_E_BADARG, "null plan");
-  int rc = check_dtype(dtype);
-  if (rc) return rc;
-  if (n_patches < 0) return zk_fail(ZK_E_BADARG, "negative patch count");
-  if (n_patches == 0) return 0;
-  if (!patches_host || !out_host) return zk_fail(ZK_E_BADARG, "null host pointer");
-  ZK_HIP(hipSetDevice(p->device));
-  const size_t in_bytes = (size_t)n_patches * p->size * p->size * elem_size(dtype);
-  const size_t out_bytes = (size_t)n_patches * p->n_poly * sizeof(double);
-  if ((rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes))) return rc;
-  if ((rc = ensure((void**)&p->d_out, &p->d_out_bytes, out_bytes))) return rc;
-  ZK_HIP(hipMemcpyAsync(p->d_in, patches_host, in_bytes, hipMemcpyHostToDevice, p->stream));
-  if ((rc = zk_transform_patches_dev(p, p->d_in, dtype, n_patches, p->d_out, p->stream))) return rc;
-  ZK_HIP(hipMemcpyAsync(out_host, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
-  ZK_HIP(hipStreamSynchronize(p->stream));
-  return 0;
-}
-
-extern "C" int zk_transform_frame(zk_plan* p, const void* image_host, int dtype, int64_t H, int64_t W,
-                                  double* out_host) {
-  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
-  int rc = check_dtype(dtype);
-  if (rc) return rc;
-  if (H <= 0 || W <= 0) return zk_fail(ZK_E_BADARG, "bad frame shape");
-  if (!image_host || !out_host) return zk_fail(ZK_E_BADARG, "null host pointer");
-  ZK_HIP(hipSetDevice(p->device));
-  const size_t in_bytes = (size_t)H * W * elem_size(dtype);
-  const size_t out_bytes = (size_t)p->n_poly * H * W * sizeof(double);
-  if ((rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes))) return rc;
-  if ((rc = ensure((void**)&p->d_out, &p->d_out_bytes, out_bytes))) return rc;
-  ZK_HIP(hipMemcpyAsync(p->d_in, image_host, in_bytes, hipMemcpyHostToDevice, p->stream));
-  if ((rc = zk_transform_frame_dev(p, p->d_in, dtype, H, W, 0, H, p->d_out, p->stream))) return rc;
-  ZK_HIP(hipMemcpyAsync(out_host, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
-  ZK_HIP(hipStreamSynchronize(p->stream));
-  return 0;
+  if (plane_stride < n_rows * W) return zk_fail(ZK_E_BADARG, "plane_stride smaller than the band");
+  p->out_plane = plane_stride;
+  const int rc = zk_transform_frame_dev(p, image, dtype, H, W, row0, n_rows, out, hip_stream);
+  p->out_plane = 0;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------
 // fused symmetry maps
 // ------------------------------------------------------------------------------------
-static int complex_count(int n_max) {
+int zk_complex_count(int n_max) {
   int k = 0;
   for (int n = 0; n <= n_max; ++n) k += n / 2 + 1;
   return k;
@@ -341,40 +301,23 @@ extern "C" int zk_frame_maps_dev(zk_plan* p, const void* image, int dtype, int64
   if (n_rows == 0) return 0;
   if (!image) return zk_fail(ZK_E_BADARG, "null device pointer");
   if (!m_unselect || n_unselect <= 0) return zk_fail(ZK_E_BADARG, "m=0 must be included in m_unselect.");
-  ZK_HIP(hipSetDevice(p->device));
+  ZK_ON_PLAN_DEVICE(p);
   return zk_launch_sep_maps(p, image, dtype, H, W, row0, n_rows, folds, n_folds, m_unselect, n_unselect, p_norm,
                             theta, n_theta, rot, ab, mirror, (hipStream_t)hip_stream);
 }
 
-extern "C" int zk_frame_maps(zk_plan* p, const void* image_host, int dtype, int64_t H, int64_t W,
-                             const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect,
-                             int p_norm, const double* theta, int n_theta, double* rot_host, double* abs_host,
-                             double* mirror_host) {
+extern "C" int zk_frame_maps_dev_strided(zk_plan* p, const void* image, int dtype, int64_t H, int64_t W, int64_t row0,
+                                         int64_t n_rows, const int32_t* folds, int n_folds,
+                                         const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta,
+                                         int n_theta, double* rot, double* ab, double* mirror, int64_t plane_stride,
+                                         void* hip_stream) {
   if (!p) return zk_fail(ZK_E_BADARG, "null plan");
-  int rc = check_dtype(dtype);
-  if (rc) return rc;
-  if (H <= 0 || W <= 0) return zk_fail(ZK_E_BADARG, "bad frame shape");
-  if (!image_host) return zk_fail(ZK_E_BADARG, "null host pointer");
-  ZK_HIP(hipSetDevice(p->device));
-  const size_t px = (size_t)H * W;
-  const int nc = complex_count(zk_full_set_nmax(p));
-  const size_t in_bytes = px * elem_size(dtype);
-  const size_t rot_d = rot_host ? (size_t)n_folds * px : 0, abs_d = abs_host ? (size_t)nc * px : 0,
-               mir_d = mirror_host ? px : 0;
-  if ((rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes))) return rc;
-  if ((rc = ensure((void**)&p->d_out, &p->d_out_bytes, (rot_d + abs_d + mir_d + 1) * sizeof(double)))) return rc;
-  double* d_rot = rot_host ? p->d_out : nullptr;
-  double* d_abs = abs_host ? p->d_out + rot_d : nullptr;
-  double* d_mir = mirror_host ? p->d_out + rot_d + abs_d : nullptr;
-  ZK_HIP(hipMemcpyAsync(p->d_in, image_host, in_bytes, hipMemcpyHostToDevice, p->stream));
-  if ((rc = zk_frame_maps_dev(p, p->d_in, dtype, H, W, 0, H, folds, n_folds, m_unselect, n_unselect, p_norm, theta,
-                              n_theta, d_rot, d_abs, d_mir, p->stream)))
-    return rc;
-  if (rot_host) ZK_HIP(hipMemcpyAsync(rot_host, d_rot, rot_d * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  if (abs_host) ZK_HIP(hipMemcpyAsync(abs_host, d_abs, abs_d * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  if (mirror_host) ZK_HIP(hipMemcpyAsync(mirror_host, d_mir, mir_d * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  ZK_HIP(hipStreamSynchronize(p->stream));
-  return 0;
+  if (plane_stride < n_rows * W) return zk_fail(ZK_E_BADARG, "plane_stride smaller than the band");
+  p->out_plane = plane_stride;
+  const int rc = zk_frame_maps_dev(p, image, dtype, H, W, row0, n_rows, folds, n_folds, m_unselect, n_unselect, p_norm,
+                                   theta, n_theta, rot, ab, mirror, hip_stream);
+  p->out_plane = 0;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------
@@ -389,7 +332,7 @@ extern "C" int zk_transform_points_dev(zk_plan* p, const void* image, int dtype,
   if (n_points < 0) return zk_fail(ZK_E_BADARG, "negative point count");
   if (n_points == 0) return 0;
   if (!image || !points || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
-  ZK_HIP(hipSetDevice(p->device));
+  ZK_ON_PLAN_DEVICE(p);
   hipStream_t s = (hipStream_t)hip_stream;
   if (zk_sep_points_available(p, dtype)) return zk_launch_sep_points(p, image, dtype, H, W, points, n_points, out, s);
   // Plans without the key-point kernel (n_max > 16, sets or bases off the separable path): cut the windows
@@ -399,7 +342,7 @@ extern "C" int zk_transform_points_dev(zk_plan* p, const void* image, int dtype,
   int64_t chunk = (int64_t)((size_t)1 << 30) / (int64_t)patch_bytes;  // <= 1 GiB of windows at a time
   if (chunk < 64) chunk = 64;
   if (chunk > n_points) chunk = n_points;
-  if ((rc = ensure(&p->d_gather, &p->d_gather_bytes, (size_t)chunk * patch_bytes))) return rc;
+  if ((rc = zk_ensure(&p->d_gather, &p->d_gather_bytes, (size_t)chunk * patch_bytes))) return rc;
   for (int64_t first = 0; first < n_points; first += chunk) {
     const int64_t n = n_points - first < chunk ? n_points - first : chunk;
     if ((rc = zk_launch_gather_points(p, image, dtype, H, W, points + 2 * first, n, p->d_gather, s))) return rc;
@@ -408,27 +351,3 @@ extern "C" int zk_transform_points_dev(zk_plan* p, const void* image, int dtype,
   return 0;
 }
 
-extern "C" int zk_transform_points(zk_plan* p, const void* image_host, int dtype, int64_t H, int64_t W,
-                                   const int32_t* points_host, int64_t n_points, double* out_host) {
-  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
-  int rc = check_dtype(dtype);
-  if (rc) return rc;
-  if (H <= 0 || W <= 0) return zk_fail(ZK_E_BADARG, "bad frame shape");
-  if (n_points < 0) return zk_fail(ZK_E_BADARG, "negative point count");
-  if (n_points == 0) return 0;
-  if (!image_host || !points_host || !out_host) return zk_fail(ZK_E_BADARG, "null host pointer");
-  ZK_HIP(hipSetDevice(p->device));
-  const size_t img_bytes = (size_t)H * W * elem_size(dtype);
-  const size_t img_pad = (img_bytes + 255) & ~(size_t)255;
-  const size_t pts_bytes = (size_t)n_points * 2 * sizeof(int32_t);
-  const size_t out_bytes = (size_t)n_points * p->n_poly * sizeof(double);
-  if ((rc = ensure(&p->d_in, &p->d_in_bytes, img_pad + pts_bytes))) return rc;
-  if ((rc = ensure((void**)&p->d_out, &p->d_out_bytes, out_bytes))) return rc;
-  int32_t* d_pts = (int32_t*)((char*)p->d_in + img_pad);
-  ZK_HIP(hipMemcpyAsync(p->d_in, image_host, img_bytes, hipMemcpyHostToDevice, p->stream));
-  ZK_HIP(hipMemcpyAsync(d_pts, points_host, pts_bytes, hipMemcpyHostToDevice, p->stream));
-  if ((rc = zk_transform_points_dev(p, p->d_in, dtype, H, W, d_pts, n_points, p->d_out, p->stream))) return rc;
-  ZK_HIP(hipMemcpyAsync(out_host, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
-  ZK_HIP(hipStreamSynchronize(p->stream));
-  return 0;
-}

@@ -1,0 +1,465 @@
+// zk_comm.hip -- the one exchange step of the multi-GPU path: in-place all-gather of row blocks on RCCL
+// (include/zernike_hip.h, "Multi-GPU").  One process per GPU; a communicator owns one ncclComm_t and one
+// HIP stream; collectives are ordered after the producer's stream and run on the communicator's stream.
+//
+// RCCL is bound at run time (dlopen / dlsym) so that libzernike_hip.so loads on machines without it and
+// never pulls a second copy of RCCL into a process that already has one (PyTorch-ROCm ships its own).
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <rccl/rccl.h>  // types and prototypes only; nothing here links against librccl
+
+#include "zk_internal.h"
+
+static_assert(ZK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+
+namespace {
+
+struct rccl_api {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+};
+
+rccl_api g_rccl;
+
+// librccl.so.1 already mapped (e.g. by torch) -> the copy next to the HIP runtime this process uses -> the
+// loader's default search -> /opt/rocm/lib
+int rccl_load() {
+  if (g_rccl.handle) return 0;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+  if (!h) {
+    Dl_info info;
+    if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+      std::string dir(info.dli_fname);
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) {
+        dir.resize(slash + 1);
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+          h = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_GLOBAL);
+          if (h) break;
+        }
+      }
+    }
+  }
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return zk_fail(ZK_E_COMM, std::string("cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "?"));
+  rccl_api a;
+  a.handle = h;
+#define ZK_SYM(field, name)                                                                 \
+  a.field = (decltype(a.field))dlsym(h, name);                                              \
+  if (!a.field) return zk_fail(ZK_E_COMM, std::string("librccl lacks the symbol ") + name)
+  ZK_SYM(GetUniqueId, "ncclGetUniqueId");
+  ZK_SYM(CommInitRank, "ncclCommInitRank");
+  ZK_SYM(CommDestroy, "ncclCommDestroy");
+  ZK_SYM(GetErrorString, "ncclGetErrorString");
+  ZK_SYM(AllGather, "ncclAllGather");
+  ZK_SYM(Broadcast, "ncclBroadcast");
+  ZK_SYM(Send, "ncclSend");
+  ZK_SYM(Recv, "ncclRecv");
+  ZK_SYM(GroupStart, "ncclGroupStart");
+  ZK_SYM(GroupEnd, "ncclGroupEnd");
+#undef ZK_SYM
+  g_rccl = a;
+  return 0;
+}
+
+int rccl_fail(ncclResult_t r, const char* what) {
+  return zk_fail(ZK_E_COMM, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
+}
+
+#define ZK_NCCL(call)                                    \
+  do {                                                   \
+    ncclResult_t zk_r_ = (call);                         \
+    if (zk_r_ != ncclSuccess) return rccl_fail(zk_r_, #call); \
+  } while (0)
+
+double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void nap_ms(int ms) {
+  timespec ts = {ms / 1000, (long)(ms % 1000) * 1000000L};
+  nanosleep(&ts, nullptr);
+}
+
+int send_all(int fd, const void* buf, size_t n) {
+  const char* p = (const char*)buf;
+  while (n) {
+    const ssize_t k = send(fd, p, n, MSG_NOSIGNAL);
+    if (k <= 0) {
+      if (k < 0 && errno == EINTR) continue;
+      return -1;
+    }
+    p += k;
+    n -= (size_t)k;
+  }
+  return 0;
+}
+
+int recv_all(int fd, void* buf, size_t n) {
+  char* p = (char*)buf;
+  while (n) {
+    const ssize_t k = recv(fd, p, n, 0);
+    if (k <= 0) {
+      if (k < 0 && errno == EINTR) continue;
+      return -1;
+    }
+    p += k;
+    n -= (size_t)k;
+  }
+  return 0;
+}
+
+}  // namespace
+
+struct zk_comm {
+  int device = 0, rank = 0, world = 1;
+  ncclComm_t nccl = nullptr;
+  hipStream_t stream = nullptr;   // collectives run here
+  hipEvent_t ev_in = nullptr;     // producer stream -> comm stream
+  hipEvent_t ev_out = nullptr;    // comm stream -> consumer stream
+  void* d_small = nullptr;        // zk_comm_allgather_host staging: world * 256 B
+  int algo = 0;                   // 0 auto, 1 p2p, 2 allgather, 3 bcast
+};
+
+extern "C" int zk_comm_rank(const zk_comm* c) { return c ? c->rank : -1; }
+extern "C" int zk_comm_world(const zk_comm* c) { return c ? c->world : 0; }
+
+extern "C" int zk_comm_unique_id(void* id_out) {
+  if (!id_out) return zk_fail(ZK_E_BADARG, "id_out is null");
+  int rc = rccl_load();
+  if (rc) return rc;
+  ncclUniqueId id;
+  ZK_NCCL(g_rccl.GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof id);
+  return 0;
+}
+
+extern "C" int zk_comm_destroy(zk_comm* c) {
+  if (!c) return 0;
+  zk_device_scope scope(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+  if (c->d_small) (void)hipFree(c->d_small);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+extern "C" int zk_comm_init_rank(int device, int rank, int world, const void* id, zk_comm** out) {
+  if (!out) return zk_fail(ZK_E_BADARG, "out is null");
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world || !id) return zk_fail(ZK_E_BADARG, "need 0 <= rank < world and an id");
+  int rc = rccl_load();
+  if (rc) return rc;
+  int ndev = 0;
+  ZK_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return zk_fail(ZK_E_BADARG, "device index out of range");
+  ZK_ON_DEVICE(device);
+  zk_comm* c = new (std::nothrow) zk_comm();
+  if (!c) return zk_fail(ZK_E_NOMEM, "out of host memory");
+  c->device = device;
+  c->rank = rank;
+  c->world = world;
+  if (const char* a = getenv("ZK_COMM_ALGO")) {
+    if (!strcmp(a, "p2p")) c->algo = 1;
+    else if (!strcmp(a, "allgather")) c->algo = 2;
+    else if (!strcmp(a, "bcast")) c->algo = 3;
+  }
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc(&c->d_small, (size_t)(world + 1) * 256);
+  if (e != hipSuccess) {
+    rc = zk_hip_fail(e, "communicator stream / events");
+    zk_comm_destroy(c);
+    return rc;
+  }
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  const ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, uid, rank);
+  if (r != ncclSuccess) {
+    c->nccl = nullptr;
+    rc = rccl_fail(r, "ncclCommInitRank");
+    zk_comm_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+// ---- rendezvous through a file (ranks of one node) ---------------------------------------------------
+extern "C" int zk_comm_init_file(int device, int rank, int world, const char* path, double timeout_s, zk_comm** out) {
+  if (!out) return zk_fail(ZK_E_BADARG, "out is null");
+  *out = nullptr;
+  if (!path || !*path) return zk_fail(ZK_E_BADARG, "path is empty");
+  if (world < 1 || rank < 0 || rank >= world) return zk_fail(ZK_E_BADARG, "need 0 <= rank < world");
+  if (timeout_s <= 0) timeout_s = 120.0;
+  char id[ZK_COMM_ID_BYTES];
+  const std::string p(path);
+  if (rank == 0) {
+    int rc = zk_comm_unique_id(id);
+    if (rc) return rc;
+    const std::string tmp = p + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return zk_fail(ZK_E_COMM, "cannot write " + tmp + ": " + strerror(errno));
+    const bool ok = fwrite(id, 1, sizeof id, f) == sizeof id;
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), p.c_str()) != 0) {
+      (void)unlink(tmp.c_str());
+      return zk_fail(ZK_E_COMM, "cannot publish " + p + ": " + strerror(errno));
+    }
+  } else {
+    const double t_end = now_s() + timeout_s;
+    for (;;) {
+      FILE* f = fopen(p.c_str(), "rb");
+      if (f) {
+        const size_t k = fread(id, 1, sizeof id, f);
+        fclose(f);
+        if (k == sizeof id) break;
+      }
+      if (now_s() > t_end) return zk_fail(ZK_E_COMM, "timed out waiting for the id file " + p);
+      nap_ms(20);
+    }
+  }
+  const int rc = zk_comm_init_rank(device, rank, world, id, out);
+  // ncclCommInitRank returns once every rank has joined: the file has served its purpose
+  if (rank == 0) (void)unlink(p.c_str());
+  return rc;
+}
+
+// ---- rendezvous over TCP: rank 0 listens, every peer connects, says its rank and receives the id ---------
+extern "C" int zk_comm_init_tcp(int device, int rank, int world, const char* host, int port, double timeout_s,
+                                zk_comm** out) {
+  if (!out) return zk_fail(ZK_E_BADARG, "out is null");
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) return zk_fail(ZK_E_BADARG, "need 0 <= rank < world");
+  if (port <= 0 || port > 65535) return zk_fail(ZK_E_BADARG, "bad port");
+  if (!host || !*host) host = "127.0.0.1";
+  if (timeout_s <= 0) timeout_s = 120.0;
+  char id[ZK_COMM_ID_BYTES];
+  const double t_end = now_s() + timeout_s;
+  if (rank == 0) {
+    int rc = zk_comm_unique_id(id);
+    if (rc) return rc;
+    if (world > 1) {
+      const int ls = socket(AF_INET, SOCK_STREAM, 0);
+      if (ls < 0) return zk_fail(ZK_E_COMM, std::string("socket: ") + strerror(errno));
+      const int one = 1;
+      setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+      sockaddr_in a = {};
+      a.sin_family = AF_INET;
+      a.sin_port = htons((uint16_t)port);
+      a.sin_addr.s_addr = htonl(INADDR_ANY);
+      if (bind(ls, (sockaddr*)&a, sizeof a) != 0 || listen(ls, world) != 0) {
+        const std::string why = strerror(errno);
+        close(ls);
+        return zk_fail(ZK_E_COMM, "cannot listen on port " + std::to_string(port) + ": " + why);
+      }
+      std::vector<char> seen((size_t)world, 0);
+      for (int got = 0; got < world - 1;) {
+        timeval tv;
+        const double left = t_end - now_s();
+        if (left <= 0) {
+          close(ls);
+          return zk_fail(ZK_E_COMM, "timed out waiting for peers to connect");
+        }
+        tv.tv_sec = (long)left;
+        tv.tv_usec = (long)((left - (double)tv.tv_sec) * 1e6);
+        fd_set fds;
+        FD_ZERO(&fds);
+        FD_SET(ls, &fds);
+        if (select(ls + 1, &fds, nullptr, nullptr, &tv) <= 0) continue;
+        const int fd = accept(ls, nullptr, nullptr);
+        if (fd < 0) continue;
+        int32_t peer = -1;
+        if (recv_all(fd, &peer, sizeof peer) == 0 && peer > 0 && peer < world && !seen[(size_t)peer] &&
+            send_all(fd, id, sizeof id) == 0) {
+          seen[(size_t)peer] = 1;
+          ++got;
+        }
+        close(fd);
+      }
+      close(ls);
+    }
+  } else {
+    addrinfo hints = {}, *res = nullptr;
+    hints.ai_family = AF_INET;
+    hints.ai_socktype = SOCK_STREAM;
+    const std::string ps = std::to_string(port);
+    if (getaddrinfo(host, ps.c_str(), &hints, &res) != 0 || !res)
+      return zk_fail(ZK_E_COMM, std::string("cannot resolve ") + host);
+    bool done = false;
+    while (!done) {
+      const int fd = socket(AF_INET, SOCK_STREAM, 0);
+      if (fd >= 0 && connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
+        const int32_t me = rank;
+        done = send_all(fd, &me, sizeof me) == 0 && recv_all(fd, id, sizeof id) == 0;
+      }
+      if (fd >= 0) close(fd);
+      if (!done) {
+        if (now_s() > t_end) {
+          freeaddrinfo(res);
+          return zk_fail(ZK_E_COMM, std::string("timed out connecting to ") + host + ":" + ps);
+        }
+        nap_ms(50);
+      }
+    }
+    freeaddrinfo(res);
+  }
+  return zk_comm_init_rank(device, rank, world, id, out);
+}
+
+// ---- the collective ------------------------------------------------------------------------------------
+namespace {
+
+// rows [lo, hi) of rank r's block that the window [row_off, row_off + n_rows) selects
+inline void window_of(int r, int64_t H, int64_t rpr, int64_t row_off, int64_t n_rows, int64_t* lo, int64_t* hi) {
+  const int64_t b0 = (int64_t)r * rpr;
+  int64_t b1 = b0 + rpr;
+  if (b1 > H) b1 = H;
+  int64_t a = b0 + row_off, z = b0 + row_off + n_rows;
+  if (z > b1) z = b1;
+  if (a > z) a = z;
+  *lo = a;
+  *hi = z;
+}
+
+}  // namespace
+
+extern "C" int zk_allgather_rows(zk_comm* c, double* full, int64_t n_planes, int64_t H, int64_t W, int64_t rpr,
+                                 int64_t row_off, int64_t n_rows, void* hip_stream) {
+  if (!c) return zk_fail(ZK_E_BADARG, "null communicator");
+  if (n_planes < 0 || H < 0 || W < 0 || rpr < 0 || row_off < 0 || n_rows < 0)
+    return zk_fail(ZK_E_BADARG, "negative extent");
+  if (rpr * (int64_t)c->world < H) return zk_fail(ZK_E_BADARG, "rows_per_rank * world does not cover the rows");
+  if (row_off + n_rows > rpr) return zk_fail(ZK_E_BADARG, "window exceeds the block");
+  if (n_planes == 0 || H == 0 || W == 0 || n_rows == 0) return 0;
+  if (!full) return zk_fail(ZK_E_BADARG, "null device pointer");
+  ZK_ON_DEVICE(c->device);
+  hipStream_t producer = (hipStream_t)hip_stream;
+  ZK_HIP(hipEventRecord(c->ev_in, producer));
+  ZK_HIP(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+  if (c->world == 1) return 0;
+  const long long plane = (long long)H * W;
+  const bool whole_equal = n_planes == 1 && row_off == 0 && n_rows == rpr && rpr * (int64_t)c->world == H;
+  int algo = c->algo;
+  if (algo == 0) algo = whole_equal ? 2 : 1;
+  if (algo == 2 && !whole_equal) algo = 1;
+  if (algo == 2) {
+    ZK_NCCL(g_rccl.AllGather(full + (long long)c->rank * rpr * W, full, (size_t)(rpr * W), ncclFloat64, c->nccl, c->stream));
+    return 0;
+  }
+  ZK_NCCL(g_rccl.GroupStart());
+  ncclResult_t r = ncclSuccess;
+  int64_t my_lo, my_hi;
+  window_of(c->rank, H, rpr, row_off, n_rows, &my_lo, &my_hi);
+  for (int64_t j = 0; j < n_planes && r == ncclSuccess; ++j) {
+    double* pl = full + j * plane;
+    if (algo == 3) {
+      for (int owner = 0; owner < c->world && r == ncclSuccess; ++owner) {
+        int64_t lo, hi;
+        window_of(owner, H, rpr, row_off, n_rows, &lo, &hi);
+        if (hi > lo) r = g_rccl.Broadcast(pl + lo * W, pl + lo * W, (size_t)((hi - lo) * W), ncclFloat64, owner, c->nccl, c->stream);
+      }
+      continue;
+    }
+    for (int step = 1; step < c->world && r == ncclSuccess; ++step) {
+      // staggered peer order: at step s every rank sends to rank + s and receives from rank - s
+      const int to = (c->rank + step) % c->world, from = (c->rank - step + c->world) % c->world;
+      int64_t lo, hi;
+      if (my_hi > my_lo) r = g_rccl.Send(pl + my_lo * W, (size_t)((my_hi - my_lo) * W), ncclFloat64, to, c->nccl, c->stream);
+      window_of(from, H, rpr, row_off, n_rows, &lo, &hi);
+      if (hi > lo && r == ncclSuccess)
+        r = g_rccl.Recv(pl + lo * W, (size_t)((hi - lo) * W), ncclFloat64, from, c->nccl, c->stream);
+    }
+  }
+  const ncclResult_t r_end = g_rccl.GroupEnd();
+  if (r != ncclSuccess) return rccl_fail(r, "grouped exchange");
+  if (r_end != ncclSuccess) return rccl_fail(r_end, "ncclGroupEnd");
+  return 0;
+}
+
+extern "C" int zk_comm_join(zk_comm* c, void* hip_stream) {
+  if (!c) return zk_fail(ZK_E_BADARG, "null communicator");
+  ZK_ON_DEVICE(c->device);
+  ZK_HIP(hipEventRecord(c->ev_out, c->stream));
+  ZK_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, c->ev_out, 0));
+  return 0;
+}
+
+extern "C" int zk_comm_allgather_host(zk_comm* c, const void* send_host, void* recv_host, int64_t bytes) {
+  if (!c) return zk_fail(ZK_E_BADARG, "null communicator");
+  if (bytes <= 0 || bytes > 256 || !send_host || !recv_host) return zk_fail(ZK_E_BADARG, "1..256 bytes per rank");
+  ZK_ON_DEVICE(c->device);
+  char* d = (char*)c->d_small;
+  char* d_send = d + (size_t)c->world * 256;
+  ZK_HIP(hipMemcpyAsync(d_send, send_host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+  if (c->world == 1) {
+    ZK_HIP(hipMemcpyAsync(d, d_send, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    ZK_NCCL(g_rccl.AllGather(d_send, d, (size_t)bytes, ncclChar, c->nccl, c->stream));
+  }
+  ZK_HIP(hipMemcpyAsync(recv_host, d, (size_t)bytes * c->world, hipMemcpyDeviceToHost, c->stream));
+  ZK_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- device memory helpers -------------------------------------------------------------------------------
+extern "C" int zk_device_malloc(int device, int64_t bytes, void** out_dev) {
+  if (!out_dev || bytes < 0) return zk_fail(ZK_E_BADARG, "bad arguments");
+  *out_dev = nullptr;
+  if (bytes == 0) return 0;
+  ZK_ON_DEVICE(device);
+  ZK_HIP(hipMalloc(out_dev, (size_t)bytes));
+  return 0;
+}
+
+extern "C" int zk_device_free(int device, void* dev) {
+  if (!dev) return 0;
+  ZK_ON_DEVICE(device);
+  ZK_HIP(hipFree(dev));
+  return 0;
+}
+
+extern "C" int zk_device_copy(int device, void* dst, const void* src, int64_t bytes, int kind) {
+  if (bytes < 0 || kind < 1 || kind > 3) return zk_fail(ZK_E_BADARG, "bad arguments");
+  if (bytes == 0) return 0;
+  if (!dst || !src) return zk_fail(ZK_E_BADARG, "null pointer");
+  ZK_ON_DEVICE(device);
+  const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  ZK_HIP(hipMemcpy(dst, src, (size_t)bytes, k));
+  return 0;
+}
+
+extern "C" int zk_device_synchronize(int device) {
+  ZK_ON_DEVICE(device);
+  ZK_HIP(hipDeviceSynchronize());
+  return 0;
+}

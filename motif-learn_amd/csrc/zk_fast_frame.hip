@@ -21,7 +21,7 @@ template <int NMAX, typename T>
 __global__ __launch_bounds__(256) void zk_frame_fold_kernel(
     const T* __restrict__ img, double* __restrict__ out, const int4* __restrict__ fpx_off,
     const double* __restrict__ ftab, const int32_t* __restrict__ colmap, int n_fpx, int K, int H, int W,
-    int row0, int n_rows, int tile_pitch) {
+    int row0, int n_rows, int tile_pitch, long long plane) {
   using S = zk_set<NMAX>;
   extern __shared__ __attribute__((aligned(16))) double tile[];
   const int tid = threadIdx.x;
@@ -63,7 +63,6 @@ __global__ __launch_bounds__(256) void zk_frame_fold_kernel(
   const int oi = i0 + wave;
   const int ok = k0 + lane;
   if (oi < row0 + n_rows && ok < W) {
-    const long long plane = (long long)n_rows * W;
     double* __restrict__ dst = out + (long long)(oi - row0) * W + ok;
     const ZK_CONST int32_t* cmap = zk_const(colmap);
 #pragma unroll
@@ -82,14 +81,16 @@ int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, i
   auto kern = zk_frame_fold_kernel<NMAX, T>;
   if (lds > 64 * 1024)
     ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if ((n_rows + 3) / 4 > 65535) return zk_fail(ZK_E_BADARG, "more than 262140 output rows per call: split the row band");
-  dim3 grid((unsigned)((W + 63) / 64), (unsigned)((n_rows + 3) / 4));
-  int rc = zk_prof_begin(p, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out, f->d_fpx_off, f->d_ftab, f->d_colmap,
-                     f->n_fpx, p->size, (int)H, (int)W, (int)row0, (int)n_rows, f->tile_pitch);
-  ZK_HIP(hipGetLastError());
-  return zk_prof_end(p, s);
+  const long long plane = zk_out_plane(p, n_rows, W);
+  return zk_for_row_bands(row0, n_rows, W, 4, [&](int64_t r0, int64_t nr, long long off) {
+    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((nr + 3) / 4));
+    int rc = zk_prof_begin(p, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out + off, f->d_fpx_off, f->d_ftab, f->d_colmap,
+                       f->n_fpx, p->size, (int)H, (int)W, (int)r0, (int)nr, f->tile_pitch, plane);
+    ZK_HIP(hipGetLastError());
+    return zk_prof_end(p, s);
+  });
 }
 
 template <typename T>

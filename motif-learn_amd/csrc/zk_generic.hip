@@ -19,7 +19,7 @@ template <typename T, int MODE, int CHUNK>  // MODE 0: batch of patches, 1: dens
 __global__ __launch_bounds__(256) void zk_generic_kernel(
     const T* __restrict__ in, double* __restrict__ out, const int2* __restrict__ pix,
     const double* __restrict__ tab, int npx, int n_poly, int n_chunks, int size, long long n_units,
-    int H, int W, int row0) {
+    int H, int W, int row0, long long plane) {
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool live = u < n_units;
   const int ea = size - 1 - (size - 1) / 2;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void zk_generic_kernel(
         if (jj < n_poly) {
           if (MODE == 1) {
             // (n_poly, n_rows, W): u already enumerates (row, col) of the band
-            out[(long long)jj * n_units + u] = acc[j];
+            out[(long long)jj * plane + u] = acc[j];
           } else {
             out[u * n_poly + jj] = acc[j];
           }
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void zk_gather_points_kernel(const T* __restri
 
 template <int MODE>
 int launch(zk_plan* p, const void* in, int dtype, long long n_units, int H, int W, int row0,
-           double* out, hipStream_t s) {
+           double* out, hipStream_t s, long long plane = 0) {
   if (n_units <= 0) return 0;
   const long long blocks = (n_units + 255) / 256;
   if (blocks > 0x7fffffffLL) return zk_fail(ZK_E_BADARG, "too many units for one launch");
@@ -96,7 +96,7 @@ int launch(zk_plan* p, const void* in, int dtype, long long n_units, int H, int 
   if (rc) return rc;
 #define ZK_GEN_LAUNCH(T, CH)                                                                              \
   hipLaunchKernelGGL((zk_generic_kernel<T, MODE, CH>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)in, out, \
-                     p->d_pix, p->d_gen_tab, p->npx, p->n_poly, p->n_chunks, p->size, n_units, H, W, row0)
+                     p->d_pix, p->d_gen_tab, p->npx, p->n_poly, p->n_chunks, p->size, n_units, H, W, row0, plane)
   if (dtype == ZK_F32) {
     if (p->gen_chunk == 64) ZK_GEN_LAUNCH(float, 64);
     else ZK_GEN_LAUNCH(float, 32);
@@ -133,5 +133,13 @@ int zk_launch_generic_patches(zk_plan* p, const void* in, int dtype, int64_t n_p
 
 int zk_launch_generic_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0,
                             int64_t n_rows, double* out, hipStream_t s) {
-  return launch<1>(p, in, dtype, n_rows * W, (int)H, (int)W, (int)row0, out, s);
+  // (n_poly, n_rows, W) unless the plan carries an output plane stride; <= 2^31 blocks of 256 pixels per launch
+  const long long plane = zk_out_plane(p, n_rows, W);
+  const int64_t cap = W > 0 ? (int64_t)0x7fffffffLL * 256 / W : n_rows;
+  for (int64_t b0 = 0; b0 < n_rows; b0 += cap) {
+    const int64_t nb = n_rows - b0 < cap ? n_rows - b0 : cap;
+    const int rc = launch<1>(p, in, dtype, nb * W, (int)H, (int)W, (int)(row0 + b0), out + b0 * W, s, plane);
+    if (rc) return rc;
+  }
+  return 0;
 }

@@ -44,14 +44,16 @@ struct zk_plan {
 
   // ---- execution state -------------------------------------------------------------
   hipStream_t stream = nullptr;  // owned; host-variant calls and default for *_dev
-  void* d_in = nullptr;          // staging for the host variants
-  size_t d_in_bytes = 0;
-  double* d_out = nullptr;
-  size_t d_out_bytes = 0;
+  struct zk_host_ring* ring = nullptr;  // staging of the host-buffer entry points (zk_host.hip)
+  size_t host_chunk = 0;                // bytes of input + output per chunk; 0 = default
   void* d_gather = nullptr;      // key points without the key-point kernel: windows cut on the device
   size_t d_gather_bytes = 0;
   double* d_scratch = nullptr;   // class-pass batch kernels (n_max > 16): [n_poly][chunk] planes
   size_t d_scratch_bytes = 0;
+  // distance in doubles between consecutive output planes of the dense / maps kernels; 0 = compact
+  // (n_rows * W).  Set for the duration of one *_strided call (zk_api.hip) so that a row band lands inside
+  // the full (planes, H, W) array -- the layout the multi-GPU gather reassembles in place.
+  long long out_plane = 0;
 
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;  // pairs: [2k] start, [2k+1] stop
@@ -68,6 +70,60 @@ int zk_hip_fail(hipError_t e, const char* what);
     hipError_t zk_e_ = (call);                         \
     if (zk_e_ != hipSuccess) return zk_hip_fail(zk_e_, #call); \
   } while (0)
+
+// every entry point runs on its plan's / communicator's device and leaves the caller's current device as it was
+struct zk_device_scope {
+  int prev = -1, dev;
+  hipError_t err = hipSuccess;
+  explicit zk_device_scope(int d) : dev(d) {
+    if (hipGetDevice(&prev) != hipSuccess) {
+      (void)hipGetLastError();
+      prev = -1;
+    }
+    if (prev != dev) err = hipSetDevice(dev);
+  }
+  ~zk_device_scope() {
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+  }
+};
+#define ZK_ON_DEVICE(d)           \
+  zk_device_scope zk_scope_(d);   \
+  if (zk_scope_.err != hipSuccess) return zk_hip_fail(zk_scope_.err, "hipSetDevice")
+#define ZK_ON_PLAN_DEVICE(p) ZK_ON_DEVICE((p)->device)
+
+static inline long long zk_out_plane(const zk_plan* p, int64_t n_rows, int64_t W) {
+  return p->out_plane ? p->out_plane : (long long)n_rows * W;
+}
+
+// A dense launch covers at most 65535 blocks of `rows_per_block` output rows (grid.y); taller bands are cut
+// into consecutive launches.  f(row0, n_rows, out_offset) with out_offset = doubles to add to the output base.
+template <class F>
+static inline int zk_for_row_bands(int64_t row0, int64_t n_rows, int64_t W, int rows_per_block, F f) {
+  const int64_t cap = (int64_t)65535 * rows_per_block;
+  for (int64_t b0 = 0; b0 < n_rows; b0 += cap) {
+    const int64_t nb = n_rows - b0 < cap ? n_rows - b0 : cap;
+    const int rc = f(row0 + b0, nb, (long long)b0 * W);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// grow-only device buffer
+static inline int zk_ensure(void** buf, size_t* have, size_t need) {
+  if (*have >= need) return 0;
+  if (*buf) {
+    ZK_HIP(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+  }
+  ZK_HIP(hipMalloc(buf, need));
+  *have = need;
+  return 0;
+}
+
+// host-buffer entry points (zk_host.hip)
+void zk_host_release(zk_plan* p);  // frees the staging ring
+int zk_complex_count(int n_max);   // number of (n, |m|) pairs (zk_api.hip)
 
 // profiling brackets (zk_api.hip)
 int zk_prof_begin(zk_plan* p, hipStream_t s);

@@ -170,8 +170,15 @@ struct zk_sep_tables {
   zk_sep_row* d_rows = nullptr;    // [n_rows]
   int32_t* d_cmin = nullptr;       // [K] first quadrant column inside the disk of window row r (Q: none); strip kernel
   int tile_pitch = 0;
-  double* d_trig = nullptr;        // fused maps: [n_theta][2][ZK_SEP_ROW] cos / sin(m theta), per call
-  size_t trig_doubles = 0;
+  // fused maps: fold weights + [n_theta][2][kernel_nmax] cos / sin(m theta).  One device table per distinct
+  // (folds, m_unselect, theta) option set, kept for the life of the plan (a few KiB each, at most
+  // ZK_TRIG_CACHE of them): a repeated call uploads nothing and never synchronises, and a launch in flight
+  // never sees its table overwritten.
+  struct trig_entry {
+    std::vector<double> host;
+    double* dev = nullptr;
+  };
+  std::vector<trig_entry> trig_cache;
   // batch kernel, one unit list per element type ([0] float32: K % 4 == 0, K >= 16; [1] float64: K even, K >= 8)
   struct batch_tables {
     int run = 0;                      // granules per source run: 8 (float32, K == 32 or wide) or 4

@@ -37,7 +37,7 @@ template <int NMAX, typename T, int MASK>
 __global__ __launch_bounds__(256, ZK_FRAME_WAVES(NMAX)) void zk_frame_sep_kernel(
     const T* __restrict__ img, double* __restrict__ out, const zk_sep_row* __restrict__ rows,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
-    int n_tab_rows, int K, int H, int W, int row0, int n_rows, int tile_pitch) {
+    int n_tab_rows, int K, int H, int W, int row0, int n_rows, int tile_pitch, long long plane) {
   extern __shared__ __attribute__((aligned(16))) double tile[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256, ZK_FRAME_WAVES(NMAX)) void zk_frame_sep_kernel
   const int oi = i0 + wave;
   const int ok = k0 + lane;
   const bool live = oi < row0 + n_rows && ok < W;
-  const long long plane = (long long)n_rows * W;
   double* __restrict__ dst = out + (long long)(oi - row0) * W + ok;
   const ZK_CONST int32_t* cmap = zk_const(colmap);
   acc.transform(zk_const(tmat), [&](auto slot, double z) {
@@ -92,14 +91,16 @@ int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, i
   auto kern = zk_frame_sep_kernel<NMAX, T, MASK>;
   if (lds > 64 * 1024)
     ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if ((n_rows + 3) / 4 > 65535) return zk_fail(ZK_E_BADARG, "more than 262140 output rows per call: split the row band");
-  dim3 grid((unsigned)((W + 63) / 64), (unsigned)((n_rows + 3) / 4));
-  int rc = zk_prof_begin(p, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out, t->d_rows, t->d_xq, t->d_T, t->d_colmap,
-                     t->n_rows, p->size, (int)H, (int)W, (int)row0, (int)n_rows, t->tile_pitch);
-  ZK_HIP(hipGetLastError());
-  return zk_prof_end(p, s);
+  const long long plane = zk_out_plane(p, n_rows, W);
+  return zk_for_row_bands(row0, n_rows, W, 4, [&](int64_t r0, int64_t nr, long long off) {
+    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((nr + 3) / 4));
+    int rc = zk_prof_begin(p, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out + off, t->d_rows, t->d_xq, t->d_T, t->d_colmap,
+                       t->n_rows, p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane);
+    ZK_HIP(hipGetLastError());
+    return zk_prof_end(p, s);
+  });
 }
 
 // n_max > 16: one launch per parity class (a quarter of the accumulators each; every launch writes the

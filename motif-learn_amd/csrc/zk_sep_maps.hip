@@ -33,6 +33,7 @@
 #endif
 
 #define ZK_MAX_FOLDS 8
+#define ZK_TRIG_CACHE 8  // device tables kept per plan, one per distinct (folds, m_unselect, theta) option set
 // waves per SIMD the register allocator is asked to fit (launch bound)
 #ifndef ZK_MAPS_2W
 #define ZK_MAPS_2W 12  // (12 at two waves: 4.23 -> 3.86 ms per 2048^2 with all outputs)
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256, ZK_MAPS_WAVES(NMAX)) void zk_frame_maps_kernel
     const T* __restrict__ img, const zk_sep_row* __restrict__ rows, const double* __restrict__ xq,
     const double* __restrict__ tmat, const double* __restrict__ trig, double* __restrict__ rot_out,
     double* __restrict__ abs_out, double* __restrict__ mirror_out, zk_maps_params prm, int n_tab_rows, int K, int H,
-    int W, int row0, int n_rows, int tile_pitch) {
+    int W, int row0, int n_rows, int tile_pitch, long long plane) {
   using Z = zk_set<NMAX>;
   extern __shared__ __attribute__((aligned(16))) double tile[];
   const int tid = threadIdx.x;
@@ -204,7 +205,6 @@ __global__ __launch_bounds__(256, ZK_MAPS_WAVES(NMAX)) void zk_frame_maps_kernel
   const int oi = i0 + wave;
   const int ok = k0 + lane;
   const bool live = oi < row0 + n_rows && ok < W;
-  const long long plane = (long long)n_rows * W;
   const long long pix = (long long)(oi - row0) * W + ok;
 
   const ZK_CONST double* tb = zk_const(tmat);
@@ -226,7 +226,7 @@ template <int NMAX>
 __global__ __launch_bounds__(256) void zk_maps_planes_kernel(const double* __restrict__ mom, const double* __restrict__ trig,
                                                              double* __restrict__ rot_out, double* __restrict__ abs_out,
                                                              double* __restrict__ mirror_out, zk_maps_params prm,
-                                                             int mom_rows, int W, int out_row0, int out_rows) {
+                                                             int mom_rows, int W, int out_row0, long long plane) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long mplane = (long long)mom_rows * W;
   const bool live = t < mplane;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void zk_maps_planes_kernel(const double* __res
           A = 0.0;
         }
       },
-      prm, trig, live, (long long)out_rows * W, pix, rot_out, abs_out, mirror_out);
+      prm, trig, live, plane, pix, rot_out, abs_out, mirror_out);
 }
 
 template <int NMAX, typename T>
@@ -254,14 +254,17 @@ int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, i
   auto kern = zk_frame_maps_kernel<NMAX, T>;
   if (lds > 64 * 1024)
     ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if ((n_rows + 3) / 4 > 65535) return zk_fail(ZK_E_BADARG, "more than 262140 output rows per call: split the row band");
-  dim3 grid((unsigned)((W + 63) / 64), (unsigned)((n_rows + 3) / 4));
-  int rc = zk_prof_begin(p, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, t->d_rows, t->d_xq, t->d_T, d_trig, rot, ab, mirror,
-                     prm, t->n_rows, p->size, (int)H, (int)W, (int)row0, (int)n_rows, t->tile_pitch);
-  ZK_HIP(hipGetLastError());
-  return zk_prof_end(p, s);
+  const long long plane = zk_out_plane(p, n_rows, W);
+  return zk_for_row_bands(row0, n_rows, W, 4, [&](int64_t r0, int64_t nr, long long off) {
+    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((nr + 3) / 4));
+    int rc = zk_prof_begin(p, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, t->d_rows, t->d_xq, t->d_T, d_trig,
+                       rot ? rot + off : nullptr, ab ? ab + off : nullptr, mirror ? mirror + off : nullptr, prm, t->n_rows,
+                       p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane);
+    ZK_HIP(hipGetLastError());
+    return zk_prof_end(p, s);
+  });
 }
 
 template <typename T>
@@ -309,18 +312,22 @@ int zk_maps_planes_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t 
     ZK_HIP(hipMalloc((void**)&p->d_scratch, need));
     p->d_scratch_bytes = need;
   }
+  const long long plane = zk_out_plane(p, n_rows, W);
   for (int64_t b0 = 0; b0 < n_rows; b0 += band) {
     const int64_t nb = n_rows - b0 < band ? n_rows - b0 : band;
+    const long long keep = p->out_plane;
+    p->out_plane = 0;  // the scratch matrix is compact
     int rc = zk_launch_sep_frame(p, in, dtype, H, W, row0 + b0, nb, p->d_scratch, s);
+    p->out_plane = keep;
     if (rc) return rc;
     if ((rc = zk_prof_begin(p, s))) return rc;
     const dim3 grid((unsigned)((nb * W + 255) / 256));
     if (p->sep->kernel_nmax == 20)
       hipLaunchKernelGGL(zk_maps_planes_kernel<20>, grid, dim3(256), 0, s, p->d_scratch, d_trig, rot, ab, mirror, prm,
-                         (int)nb, (int)W, (int)b0, (int)n_rows);
+                         (int)nb, (int)W, (int)b0, plane);
     else
       hipLaunchKernelGGL(zk_maps_planes_kernel<24>, grid, dim3(256), 0, s, p->d_scratch, d_trig, rot, ab, mirror, prm,
-                         (int)nb, (int)W, (int)b0, (int)n_rows);
+                         (int)nb, (int)W, (int)b0, plane);
     ZK_HIP(hipGetLastError());
     if ((rc = zk_prof_end(p, s))) return rc;
   }
@@ -344,7 +351,7 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
                        const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
                        const double* theta, int n_theta, double* rot, double* ab, double* mirror, hipStream_t s) {
   if (!zk_sep_maps_available(p, dtype))
-    return zk_fail(ZK_E_BADARG, "plan has no symmetry-map kernels (needs the separable tables: n_max <= 20)");
+    return zk_fail(ZK_E_BADARG, "plan has no symmetry-map kernels (needs the separable tables: full Zernike set, n_max <= 24)");
   if (n_folds < 0 || n_folds > ZK_MAX_FOLDS) return zk_fail(ZK_E_BADARG, "at most 8 folds per call");
   if (p_norm != 0 && p_norm != 2) return zk_fail(ZK_E_BADARG, "p must be 2 or 0 (None)");
   if (rot && (!folds || n_folds == 0)) return zk_fail(ZK_E_BADARG, "rot output requested without folds");
@@ -390,19 +397,34 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
       }
   }
   zk_sep_tables* t = p->sep;
-  if (t->trig_doubles < tab.size()) {
-    ZK_HIP(hipStreamSynchronize(s));  // a previous launch may still read the old table
-    if (t->d_trig) ZK_HIP(hipFree(t->d_trig));
-    t->d_trig = nullptr;
-    t->trig_doubles = 0;
-    ZK_HIP(hipMalloc((void**)&t->d_trig, tab.size() * sizeof(double)));
-    t->trig_doubles = tab.size();
+  const double* d_trig = nullptr;
+  for (size_t k = 0; k < t->trig_cache.size() && !d_trig; ++k)
+    if (t->trig_cache[k].host == tab) {
+      d_trig = t->trig_cache[k].dev;
+      if (k) std::swap(t->trig_cache[k], t->trig_cache[k - 1]);  // drift towards the front: eviction takes the back
+    }
+  if (!d_trig) {
+    // a new option set: a blocking upload into a fresh table (first call with these options only -- repeated
+    // calls never synchronise).  When the cache is full the least recently used table goes, after the device
+    // has drained (some launch may still read it).
+    if (t->trig_cache.size() >= ZK_TRIG_CACHE) {
+      ZK_HIP(hipDeviceSynchronize());
+      if (t->trig_cache.back().dev) (void)hipFree(t->trig_cache.back().dev);
+      t->trig_cache.pop_back();
+    }
+    zk_sep_tables::trig_entry e;
+    ZK_HIP(hipMalloc((void**)&e.dev, tab.size() * sizeof(double)));
+    hipError_t he = hipMemcpy(e.dev, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+      (void)hipFree(e.dev);
+      return zk_hip_fail(he, "hipMemcpy(trig table)");
+    }
+    e.host = std::move(tab);
+    d_trig = e.dev;
+    t->trig_cache.insert(t->trig_cache.begin(), std::move(e));
   }
-  // stream-ordered upload from a pageable stack-lifetime buffer: synchronise before it goes away
-  ZK_HIP(hipMemcpyAsync(t->d_trig, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  ZK_HIP(hipStreamSynchronize(s));
-  if (knm > 16) return zk_maps_planes_g2(p, in, dtype, H, W, row0, n_rows, prm, t->d_trig, rot, ab, mirror, s);
-  if (knm > 12) return zk_maps_dispatch_g1(p, in, dtype, H, W, row0, n_rows, prm, t->d_trig, rot, ab, mirror, s);
-  return zk_maps_dispatch(p, in, dtype, H, W, row0, n_rows, prm, t->d_trig, rot, ab, mirror, s);
+  if (knm > 16) return zk_maps_planes_g2(p, in, dtype, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+  if (knm > 12) return zk_maps_dispatch_g1(p, in, dtype, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+  return zk_maps_dispatch(p, in, dtype, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
 }
 #endif

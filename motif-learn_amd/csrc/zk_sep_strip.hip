@@ -30,7 +30,7 @@ template <int NMAX, typename T>
 __global__ __launch_bounds__(256, 2) void zk_frame_strip_kernel(
     const T* __restrict__ img, double* __restrict__ out, const int32_t* __restrict__ cmin_tab,
     const double* __restrict__ xq, const double* __restrict__ pfull, const double* __restrict__ tmat,
-    const int32_t* __restrict__ colmap, int K, int H, int W, int row0, int n_rows, int tile_pitch) {
+    const int32_t* __restrict__ colmap, int K, int H, int W, int row0, int n_rows, int tile_pitch, long long plane) {
   using S = zk_sep_set<NMAX>;
   constexpr int YROW = ZK_STREAM_ROW(NMAX);
   extern __shared__ __attribute__((aligned(16))) double tile[];
@@ -127,7 +127,6 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip_kernel(
   for (int fr = half; fr <= K; ++fr) frame_row(fr, std::false_type{});
 
   const int ok = k0 + lane;
-  const long long plane = (long long)n_rows * W;
   const ZK_CONST int32_t* cmap = zk_const(colmap);
   const ZK_CONST double* tb = zk_const(tmat);
   {
@@ -158,14 +157,16 @@ int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, i
   auto kern = zk_frame_strip_kernel<NMAX, T>;
   if (lds > 64 * 1024)
     ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if ((n_rows + 7) / 8 > 65535) return zk_fail(ZK_E_BADARG, "too many output rows per call: split the row band");
-  dim3 grid((unsigned)((W + 63) / 64), (unsigned)((n_rows + 7) / 8));
-  int rc = zk_prof_begin(p, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out, t->d_cmin, t->d_xq, t->d_pfull, t->d_T, t->d_colmap,
-                     p->size, (int)H, (int)W, (int)row0, (int)n_rows, t->tile_pitch);
-  ZK_HIP(hipGetLastError());
-  return zk_prof_end(p, s);
+  const long long plane = zk_out_plane(p, n_rows, W);
+  return zk_for_row_bands(row0, n_rows, W, 8, [&](int64_t r0, int64_t nr, long long off) {
+    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((nr + 7) / 8));
+    int rc = zk_prof_begin(p, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out + off, t->d_cmin, t->d_xq, t->d_pfull, t->d_T,
+                       t->d_colmap, p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane);
+    ZK_HIP(hipGetLastError());
+    return zk_prof_end(p, s);
+  });
 }
 
 template <typename T>

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
+import weakref
 from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 
 import numpy as np
@@ -48,6 +50,29 @@ SYMBOLS = {
     "zk_frame_maps_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, POINTER(c_int32),
                                   c_int, POINTER(c_int32), c_int, c_int, POINTER(c_double), c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
+    "zk_transform_frame_dev_strided": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
+                                               c_void_p, c_int64, c_void_p]),
+    "zk_frame_maps_dev_strided": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
+                                          POINTER(c_int32), c_int, POINTER(c_int32), c_int, c_int, POINTER(c_double),
+                                          c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "zk_plan_set_host_chunk": (c_int, [c_void_p, c_int64]),
+    "zk_plan_release_staging": (c_int, [c_void_p]),
+    "zk_host_alloc": (c_int, [c_int64, POINTER(c_void_p)]),
+    "zk_host_free": (c_int, [c_void_p]),
+    "zk_comm_unique_id": (c_int, [c_void_p]),
+    "zk_comm_init_rank": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    "zk_comm_init_file": (c_int, [c_int, c_int, c_int, c_char_p, c_double, POINTER(c_void_p)]),
+    "zk_comm_init_tcp": (c_int, [c_int, c_int, c_int, c_char_p, c_int, c_double, POINTER(c_void_p)]),
+    "zk_comm_destroy": (c_int, [c_void_p]),
+    "zk_comm_rank": (c_int, [c_void_p]),
+    "zk_comm_world": (c_int, [c_void_p]),
+    "zk_allgather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "zk_comm_join": (c_int, [c_void_p, c_void_p]),
+    "zk_comm_allgather_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    "zk_device_malloc": (c_int, [c_int, c_int64, POINTER(c_void_p)]),
+    "zk_device_free": (c_int, [c_int, c_void_p]),
+    "zk_device_copy": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int]),
+    "zk_device_synchronize": (c_int, [c_int]),
     "zk_plan_profile": (c_int, [c_void_p, c_int]),
     "zk_plan_profile_read": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
 }
@@ -120,6 +145,63 @@ def dtype_code(dtype):
     return None
 
 
+class PinnedPool:
+    """Page-locked host arrays for results, recycled.
+
+    ``ZPs.transform`` returns arrays of hundreds of MB to GB; filling a fresh ``np.empty`` over PCIe pays a page
+    fault per 4 KiB and the runtime's pageable staging.  Arrays from this pool are page-locked (``zk_host_alloc``
+    = ``hipHostMalloc``): the device writes them by DMA at link speed.  A block returns to the pool when the last
+    NumPy view of it is garbage-collected and is handed out again for the next result of a fitting size, so
+    repeated calls neither allocate nor fault.  ``MTFLEARN_AMD_PINNED_MB`` caps the idle bytes the pool keeps
+    (default 16384; 0 disables the pool: results are plain ``np.empty`` arrays)."""
+
+    GRAIN = 2 << 20
+
+    def __init__(self):
+        self._free = []            # [(capacity, ptr)]
+        self._lock = threading.Lock()
+        self.max_idle = int(os.environ.get("MTFLEARN_AMD_PINNED_MB", "16384")) << 20
+        self.min_bytes = 1 << 20   # smaller results are not worth a pinned block
+
+    def empty(self, shape, dtype=np.float64):
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if self.max_idle <= 0 or nbytes < self.min_bytes:
+            return np.empty(shape, dtype=dtype)
+        cap = -(-nbytes // self.GRAIN) * self.GRAIN
+        ptr = None
+        with self._lock:
+            fits = [k for k, (c, _) in enumerate(self._free) if cap <= c <= 2 * cap]
+            if fits:
+                cap, ptr = self._free.pop(min(fits, key=lambda k: self._free[k][0]))
+        if ptr is None:
+            handle = c_void_p()
+            if load().zk_host_alloc(cap, byref(handle)) != 0:     # no pinned memory to be had: pageable result
+                return np.empty(shape, dtype=dtype)
+            ptr = handle.value
+        buf = (ctypes.c_char * cap).from_address(ptr)
+        weakref.finalize(buf, self._release, cap, ptr)
+        return np.ndarray(shape, dtype=dtype, buffer=buf)
+
+    def _release(self, cap, ptr):
+        with self._lock:
+            if sum(c for c, _ in self._free) + cap <= self.max_idle:
+                self._free.append((cap, ptr))
+                return
+        if _lib is not None:
+            _lib.zk_host_free(c_void_p(ptr))
+
+    def trim(self):
+        """Give every idle block back to the system."""
+        with self._lock:
+            blocks, self._free = self._free, []
+        for _, ptr in blocks:
+            load().zk_host_free(c_void_p(ptr))
+
+
+pinned = PinnedPool()
+
+
 class Plan:
     """Owns one ``zk_plan`` (device tables for one basis on one GPU)."""
 
@@ -180,7 +262,7 @@ class Plan:
     # -- host-buffer entry points --------------------------------------------------------
     def transform_patches(self, patches):
         code = dtype_code(patches.dtype)
-        out = np.empty((patches.shape[0], self.n_poly), dtype=np.float64)
+        out = pinned.empty((patches.shape[0], self.n_poly))
         check(self._lib.zk_transform_patches(self._h, patches.ctypes.data_as(c_void_p), code,
                                              patches.shape[0], out.ctypes.data_as(POINTER(c_double))),
               "zk_transform_patches")
@@ -189,7 +271,7 @@ class Plan:
     def transform_frame(self, image):
         code = dtype_code(image.dtype)
         h, w = image.shape
-        out = np.empty((self.n_poly, h, w), dtype=np.float64)
+        out = pinned.empty((self.n_poly, h, w))
         check(self._lib.zk_transform_frame(self._h, image.ctypes.data_as(c_void_p), code, h, w,
                                            out.ctypes.data_as(POINTER(c_double))),
               "zk_transform_frame")
@@ -200,7 +282,7 @@ class Plan:
         code = dtype_code(image.dtype)
         h, w = image.shape
         pts = np.ascontiguousarray(points, dtype=np.int32).reshape(-1, 2)
-        out = np.empty((pts.shape[0], self.n_poly), dtype=np.float64)
+        out = pinned.empty((pts.shape[0], self.n_poly))
         check(self._lib.zk_transform_points(self._h, image.ctypes.data_as(c_void_p), code, h, w,
                                             pts.ctypes.data_as(POINTER(c_int32)), pts.shape[0],
                                             out.ctypes.data_as(POINTER(c_double))), "zk_transform_points")
@@ -212,10 +294,10 @@ class Plan:
         h, w = image.shape
         folds32 = np.ascontiguousarray(folds if folds is not None else [], dtype=np.int32)
         unsel32 = np.ascontiguousarray(m_unselect, dtype=np.int32)
-        rot = np.empty((len(folds32), h, w)) if len(folds32) else None
-        ab = np.empty((n_complex, h, w)) if want_abs else None
+        rot = pinned.empty((len(folds32), h, w)) if len(folds32) else None
+        ab = pinned.empty((n_complex, h, w)) if want_abs else None
         th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
-        mir = np.empty((h, w)) if th is not None else None
+        mir = pinned.empty((h, w)) if th is not None else None
         ptr = lambda a: a.ctypes.data_as(c_void_p) if a is not None else None
         check(self._lib.zk_frame_maps(
             self._h, image.ctypes.data_as(c_void_p), code, h, w,
@@ -226,16 +308,20 @@ class Plan:
         return rot, ab, mir
 
     def frame_maps_dev(self, image_ptr, code, height, width, row0, n_rows, folds, m_unselect, p, theta,
-                       rot_ptr, abs_ptr, mirror_ptr, stream=0):
+                       rot_ptr, abs_ptr, mirror_ptr, stream=0, plane_stride=None):
         folds32 = np.ascontiguousarray(folds if folds is not None else [], dtype=np.int32)
         unsel32 = np.ascontiguousarray(m_unselect, dtype=np.int32)
         th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
-        check(self._lib.zk_frame_maps_dev(
-            self._h, c_void_p(image_ptr), code, height, width, row0, n_rows,
-            folds32.ctypes.data_as(POINTER(c_int32)), len(folds32),
-            unsel32.ctypes.data_as(POINTER(c_int32)), len(unsel32), 2 if p == 2 else 0,
-            th.ctypes.data_as(POINTER(c_double)) if th is not None else None, 0 if th is None else len(th),
-            c_void_p(rot_ptr), c_void_p(abs_ptr), c_void_p(mirror_ptr), c_void_p(stream)), "zk_frame_maps_dev")
+        head = (self._h, c_void_p(image_ptr), code, height, width, row0, n_rows,
+                folds32.ctypes.data_as(POINTER(c_int32)), len(folds32),
+                unsel32.ctypes.data_as(POINTER(c_int32)), len(unsel32), 2 if p == 2 else 0,
+                th.ctypes.data_as(POINTER(c_double)) if th is not None else None, 0 if th is None else len(th),
+                c_void_p(rot_ptr), c_void_p(abs_ptr), c_void_p(mirror_ptr))
+        if plane_stride is None:
+            check(self._lib.zk_frame_maps_dev(*head, c_void_p(stream)), "zk_frame_maps_dev")
+        else:
+            check(self._lib.zk_frame_maps_dev_strided(*head, plane_stride, c_void_p(stream)),
+                  "zk_frame_maps_dev_strided")
 
     # -- device-pointer entry points (bench / multi-GPU harness) ------------------------------
     def transform_patches_dev(self, patches_ptr, code, n_patches, out_ptr, stream=0):
@@ -243,7 +329,78 @@ class Plan:
                                                  c_void_p(out_ptr), c_void_p(stream)),
               "zk_transform_patches_dev")
 
-    def transform_frame_dev(self, image_ptr, code, height, width, row0, n_rows, out_ptr, stream=0):
-        check(self._lib.zk_transform_frame_dev(self._h, c_void_p(image_ptr), code, height, width, row0,
-                                               n_rows, c_void_p(out_ptr), c_void_p(stream)),
-              "zk_transform_frame_dev")
+    def transform_frame_dev(self, image_ptr, code, height, width, row0, n_rows, out_ptr, stream=0, plane_stride=None):
+        """Row band -> (n_poly, n_rows, W) at ``out_ptr``; with ``plane_stride`` (doubles) the planes are that far
+        apart, i.e. the band is written in place into a larger (n_poly, H, W) array."""
+        if plane_stride is None:
+            check(self._lib.zk_transform_frame_dev(self._h, c_void_p(image_ptr), code, height, width, row0,
+                                                   n_rows, c_void_p(out_ptr), c_void_p(stream)),
+                  "zk_transform_frame_dev")
+        else:
+            check(self._lib.zk_transform_frame_dev_strided(self._h, c_void_p(image_ptr), code, height, width, row0,
+                                                           n_rows, c_void_p(out_ptr), plane_stride, c_void_p(stream)),
+                  "zk_transform_frame_dev_strided")
+
+    def set_host_chunk(self, chunk_bytes):
+        check(self._lib.zk_plan_set_host_chunk(self._h, int(chunk_bytes)), "zk_plan_set_host_chunk")
+
+    def release_staging(self):
+        """Free the staging buffers the host-buffer entry points have grown (re-created on demand)."""
+        check(self._lib.zk_plan_release_staging(self._h), "zk_plan_release_staging")
+
+
+class Comm:
+    """Owns one ``zk_comm``: this process's endpoint of the RCCL communicator (one process per GPU).
+
+    Rendezvous: ``Comm(device, rank, world, path=...)`` -- ranks of one node meet through a file rank 0
+    writes; ``host=/port=`` -- rank 0 listens on a TCP port; ``unique_id=`` -- the caller moved the
+    128-byte id from rank 0 (``Comm.unique_id()``) to the others by its own means."""
+
+    ID_BYTES = 128
+
+    def __init__(self, device, rank, world, path=None, host=None, port=None, unique_id=None, timeout=120.0):
+        lib = load()
+        handle = c_void_p()
+        self.device, self.rank, self.world = int(device), int(rank), int(world)
+        if unique_id is not None:
+            buf = ctypes.create_string_buffer(bytes(unique_id), self.ID_BYTES)
+            check(lib.zk_comm_init_rank(self.device, self.rank, self.world, buf, byref(handle)), "zk_comm_init_rank")
+        elif path is not None:
+            check(lib.zk_comm_init_file(self.device, self.rank, self.world, os.fsencode(path), float(timeout),
+                                        byref(handle)), "zk_comm_init_file")
+        elif port is not None:
+            check(lib.zk_comm_init_tcp(self.device, self.rank, self.world, (host or "127.0.0.1").encode(), int(port),
+                                       float(timeout), byref(handle)), "zk_comm_init_tcp")
+        else:
+            raise ValueError("Comm needs one of path=, port= or unique_id=")
+        self._h, self._lib = handle, lib
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(Comm.ID_BYTES)
+        check(load().zk_comm_unique_id(buf), "zk_comm_unique_id")
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.zk_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def allgather_rows(self, full_ptr, n_planes, height, width, rows_per_rank, row_off, n_rows, stream=0):
+        """In-place all-gather of the row window ``[row_off, row_off+n_rows)`` of every rank's block of the
+        ``(n_planes, height, width)`` float64 array at ``full_ptr`` (see ``zk_allgather_rows``)."""
+        check(self._lib.zk_allgather_rows(self._h, c_void_p(full_ptr), n_planes, height, width, rows_per_rank,
+                                          row_off, n_rows, c_void_p(stream)), "zk_allgather_rows")
+
+    def join(self, stream=0):
+        check(self._lib.zk_comm_join(self._h, c_void_p(stream)), "zk_comm_join")
+
+    def allgather_host(self, payload: bytes):
+        """Blocking all-gather of up to 256 host bytes per rank; returns the list of every rank's bytes."""
+        n = len(payload)
+        send = ctypes.create_string_buffer(payload, n)
+        recv = ctypes.create_string_buffer(n * self.world)
+        check(self._lib.zk_comm_allgather_host(self._h, send, recv, n), "zk_comm_allgather_host")
+        return [recv.raw[r * n:(r + 1) * n] for r in range(self.world)]

@@ -1,23 +1,37 @@
-"""Multi-GPU sharding of the Zernike hot path: one process per GPU, one all-gather.
+"""Multi-GPU sharding of the Zernike hot path: one process per GPU, one exchange step.
 
-Every output vector depends on one K x K window only, so the path shards with no halo exchange
-(SURVEY 8e): a batch of patches splits into contiguous equal blocks, a frame into contiguous
-row bands (the frame itself is small and replicated).  The only collective is the all-gather
-that reassembles the moment matrix on every rank -- ``torch.distributed`` with the ``nccl``
-backend, which on ROCm is RCCL over xGMI; the same code runs on ``gloo`` for the CPU tests.
+Every output vector depends on one K x K window only, so the path shards with no halo exchange and no
+data-path collective: a batch of patches splits into contiguous equal blocks
+(:func:`shard_bounds`), a frame into contiguous row bands (the frame itself is small and replicated), a batch
+of frames into whole frames.  The only exchange is the all-gather that reassembles the result on every rank.
 
-torch is used for device memory, streams and the collective only; the arithmetic is
-``libzernike_hip.so`` called on raw device pointers.
+Layout is chosen so that the gather needs no copy on either side: every rank holds the FULL result array
+(``(N, n_poly)``, ``(n_poly, H, W)``, ``(planes, H, W)`` maps or ``(F, n_poly, H, W)``), its kernels write
+its own block straight into place (dense kernels through their plane stride), and the collective fills in the
+other blocks in place (``zk_allgather_rows``).  The drivers below cut a rank's block into chunks and issue
+kernel(c+1) while the transfer of chunk c runs on the communicator's own stream.
+
+Two communicators share one interface:
+
+* :class:`RcclComm` -- the product: ``zk_comm_*`` / ``zk_allgather_rows`` of ``libzernike_hip.so`` on RCCL
+  (no ``torch.distributed`` involved; rendezvous through a file, a TCP port, or an id the caller moved).
+* :class:`TorchComm` -- a test aid on ``torch.distributed`` (``gloo`` on CPU for the world-size-2 tests and
+  for rehearsing the control flow with two ranks on one GPU).
+
+torch is used for device memory and streams only; the arithmetic is ``libzernike_hip.so`` called on raw
+device pointers.
 """
 from __future__ import annotations
+
+import struct
 
 import numpy as np
 
 from . import _native
 
-__all__ = ["shard_bounds", "allgather_patch_moments", "allgather_frame_moments",
-           "patch_moments_device", "frame_moments_device", "frame_maps_device",
-           "sharded_patch_moments", "sharded_frame_moments"]
+__all__ = ["shard_bounds", "RcclComm", "TorchComm", "DeviceCompute", "patch_moments_device",
+           "frame_moments_device", "frame_maps_device", "sharded_patch_moments", "sharded_frame_moments",
+           "sharded_frame_maps", "sharded_frames_moments", "allgather_patch_moments", "allgather_frame_moments"]
 
 
 def shard_bounds(n_units: int, rank: int, world: int):
@@ -31,61 +45,309 @@ def shard_bounds(n_units: int, rank: int, world: int):
     return start, count, padded
 
 
+def _chunk_bounds(padded: int, n_chunks: int):
+    """Cut ``[0, padded)`` into at most ``n_chunks`` consecutive non-empty windows (same on every rank)."""
+    n_chunks = max(1, min(int(n_chunks), padded)) if padded > 0 else 1
+    edges = [padded * c // n_chunks for c in range(n_chunks + 1)]
+    return [(edges[c], edges[c + 1]) for c in range(n_chunks) if edges[c + 1] > edges[c]]
+
+
 def _current_stream_ptr(tensor):
     import torch
     return torch.cuda.current_stream(tensor.device).cuda_stream if tensor.is_cuda else 0
 
 
+def _dtype_code(tensor):
+    """ZK_F32 / ZK_F64 of a torch tensor; anything else is an error (the kernels would read it as float64)."""
+    import torch
+    if tensor.dtype == torch.float32:
+        return _native.ZK_F32
+    if tensor.dtype == torch.float64:
+        return _native.ZK_F64
+    raise TypeError(f"the device entry points take float32 or float64 tensors, not {tensor.dtype}; convert first "
+                    "(ZPs.transform does that for NumPy input)")
+
+
+def _check_operand(plan, tensor, what):
+    if not tensor.is_cuda:
+        raise ValueError(f"{what} must live on the GPU")
+    if not tensor.is_contiguous():
+        raise ValueError(f"{what} must be contiguous")
+    if tensor.device.index != plan.device:
+        raise ValueError(f"{what} is on cuda:{tensor.device.index} but the plan was created on device {plan.device}: "
+                         "create the plan on the tensor's device (MTFLEARN_AMD_DEVICE / ZPs.to_device)")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# single-GPU device entry points on torch tensors
+# ---------------------------------------------------------------------------------------------------------
 def patch_moments_device(plan: "_native.Plan", patches, out=None):
     """Run the batch kernel on a CUDA/HIP torch tensor ``(N, K, K)`` (float32/float64) on torch's
     current stream; returns the ``(N, n_poly)`` float64 tensor (no host copies)."""
     import torch
-    assert patches.is_cuda and patches.is_contiguous()
-    code = _native.ZK_F32 if patches.dtype == torch.float32 else _native.ZK_F64
+    _check_operand(plan, patches, "patches")
+    code = _dtype_code(patches)
     n = patches.shape[0]
     if out is None:
         out = torch.empty((n, plan.n_poly), dtype=torch.float64, device=patches.device)
+    else:
+        _check_operand(plan, out, "out")
     plan.transform_patches_dev(patches.data_ptr(), code, n, out.data_ptr(), _current_stream_ptr(patches))
     return out
 
 
-def frame_moments_device(plan: "_native.Plan", image, row0=0, n_rows=None, out=None):
-    """Run the dense kernel for output rows ``[row0, row0+n_rows)`` of a CUDA/HIP torch frame
-    ``(H, W)``; returns ``(n_poly, n_rows, W)`` float64."""
+def frame_moments_device(plan: "_native.Plan", image, row0=0, n_rows=None, out=None, full=None):
+    """Run the dense kernel for output rows ``[row0, row0+n_rows)`` of a CUDA/HIP torch frame ``(H, W)``.
+    Returns ``(n_poly, n_rows, W)`` float64 -- or, with ``full`` (an ``(n_poly, H, W)`` tensor), writes the
+    band in place into it and returns ``full``."""
     import torch
-    assert image.is_cuda and image.is_contiguous()
-    code = _native.ZK_F32 if image.dtype == torch.float32 else _native.ZK_F64
+    _check_operand(plan, image, "image")
+    code = _dtype_code(image)
     h, w = image.shape
     n_rows = h - row0 if n_rows is None else n_rows
+    stream = _current_stream_ptr(image)
+    if full is not None:
+        _check_operand(plan, full, "full")
+        assert tuple(full.shape) == (plan.n_poly, h, w) and full.dtype == torch.float64
+        plan.transform_frame_dev(image.data_ptr(), code, h, w, row0, n_rows, full.data_ptr() + row0 * w * 8, stream,
+                                 plane_stride=h * w)
+        return full
     if out is None:
         out = torch.empty((plan.n_poly, n_rows, w), dtype=torch.float64, device=image.device)
-    plan.transform_frame_dev(image.data_ptr(), code, h, w, row0, n_rows, out.data_ptr(),
-                             _current_stream_ptr(image))
+    else:
+        _check_operand(plan, out, "out")
+    plan.transform_frame_dev(image.data_ptr(), code, h, w, row0, n_rows, out.data_ptr(), stream)
     return out
 
 
 def frame_maps_device(plan: "_native.Plan", image, n_complex, folds=(2, 3, 4, 6), m_unselect=(0, 1), p=2,
-                      theta=None, want_abs=True, row0=0, n_rows=None):
+                      theta=None, want_abs=True, row0=0, n_rows=None, full=None):
     """Fused frame -> symmetry maps for output rows ``[row0, row0+n_rows)`` of a CUDA/HIP torch frame.
     Returns ``(rot, abs, mirror)`` float64 tensors of shapes ``(len(folds), n_rows, W)``,
-    ``(n_complex, n_rows, W)``, ``(n_rows, W)`` (``None`` for outputs not requested).  Row bands of
-    these maps are what the multi-GPU pipeline all-gathers (``allgather_frame_moments`` works on any
-    ``(planes, rows, W)`` tensor): 41 planes instead of the 66 moment planes at n_max = 10."""
+    ``(n_complex, n_rows, W)``, ``(n_rows, W)`` (``None`` for outputs not requested).  With
+    ``full = (rot_full, abs_full, mirror_full)`` (whole-frame tensors, entries ``None`` where not wanted) the
+    band is written in place into them and ``full`` is returned."""
     import torch
-    assert image.is_cuda and image.is_contiguous()
-    code = _native.ZK_F32 if image.dtype == torch.float32 else _native.ZK_F64
+    _check_operand(plan, image, "image")
+    code = _dtype_code(image)
     h, w = image.shape
     n_rows = h - row0 if n_rows is None else n_rows
+    stream = _current_stream_ptr(image)
+    if full is not None:
+        ptr = lambda t: t.data_ptr() + row0 * w * 8 if t is not None else 0
+        plan.frame_maps_dev(image.data_ptr(), code, h, w, row0, n_rows, folds if full[0] is not None else None,
+                            m_unselect, p, theta if full[2] is not None else None, ptr(full[0]), ptr(full[1]),
+                            ptr(full[2]), stream, plane_stride=h * w)
+        return full
     mk = lambda planes: torch.empty((planes, n_rows, w), dtype=torch.float64, device=image.device)
     rot = mk(len(folds)) if folds is not None and len(folds) else None
     ab = mk(n_complex) if want_abs else None
     mir = torch.empty((n_rows, w), dtype=torch.float64, device=image.device) if theta is not None else None
     ptr = lambda t: t.data_ptr() if t is not None else 0
     plan.frame_maps_dev(image.data_ptr(), code, h, w, row0, n_rows, folds, m_unselect, p, theta,
-                        ptr(rot), ptr(ab), ptr(mir), _current_stream_ptr(image))
+                        ptr(rot), ptr(ab), ptr(mir), stream)
     return rot, ab, mir
 
 
+# ---------------------------------------------------------------------------------------------------------
+# communicators
+# ---------------------------------------------------------------------------------------------------------
+class RcclComm:
+    """This process's endpoint of the RCCL communicator inside ``libzernike_hip.so`` (``zk_comm_*``).
+
+    ``RcclComm(device, rank, world, path=...)`` (ranks of one node meet through a file), ``port=`` (TCP) or
+    ``unique_id=``; see :class:`mtflearn_amd._native.Comm`."""
+
+    def __init__(self, device, rank, world, **rendezvous):
+        self._c = _native.Comm(device, rank, world, **rendezvous)
+        self.rank, self.world, self.device = self._c.rank, self._c.world, self._c.device
+
+    def allgather_rows(self, full, n_planes, height, width, rows_per_rank, row_off, n_rows, stream=0):
+        if not full.is_cuda or full.device.index != self.device or not full.is_contiguous():
+            raise ValueError("the gathered array must be a contiguous tensor on the communicator's device")
+        if full.element_size() != 8 or full.numel() != n_planes * height * width:
+            raise ValueError("the gathered array must hold n_planes * height * width float64 values")
+        self._c.allgather_rows(full.data_ptr(), n_planes, height, width, rows_per_rank, row_off, n_rows, stream)
+
+    def join(self, stream=0):
+        self._c.join(stream)
+
+    def allgather_host(self, payload: bytes):
+        return self._c.allgather_host(payload)
+
+    def max_over_ranks(self, value: float) -> float:
+        return max(struct.unpack("d", b)[0] for b in self.allgather_host(struct.pack("d", float(value))))
+
+    def barrier(self):
+        self.allgather_host(b"\0")
+
+    def close(self):
+        self._c.close()
+
+
+class TorchComm:
+    """Same interface on ``torch.distributed`` -- a TEST AID (``gloo`` on CPU tensors for the world-size-2
+    tests, ``gloo`` on GPU tensors to rehearse two ranks on one GPU).  Blocking; ``stream`` is ignored."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist, self._group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allgather_rows(self, full, n_planes, height, width, rows_per_rank, row_off, n_rows, stream=0):
+        if full.is_cuda:
+            import torch
+            torch.cuda.current_stream(full.device).synchronize()
+        view = full.view(n_planes, height, width)
+        for owner in range(self.world):
+            b0 = owner * rows_per_rank
+            lo = min(b0 + row_off, height)
+            hi = min(b0 + row_off + n_rows, min(b0 + rows_per_rank, height))
+            if hi <= lo:
+                continue
+            piece = view[:, lo:hi, :].contiguous()
+            self._dist.broadcast(piece, src=owner if self._group is None else self._dist.get_global_rank(self._group, owner),
+                                 group=self._group)
+            if owner != self.rank:
+                view[:, lo:hi, :].copy_(piece)
+
+    def join(self, stream=0):
+        pass
+
+    def allgather_host(self, payload: bytes):
+        out = [None] * self.world
+        self._dist.all_gather_object(out, payload, group=self._group)
+        return out
+
+    def max_over_ranks(self, value: float) -> float:
+        return max(struct.unpack("d", b)[0] for b in self.allgather_host(struct.pack("d", float(value))))
+
+    def barrier(self):
+        self._dist.barrier(group=self._group)
+
+    def close(self):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------------------
+# what a driver asks of "the kernels": the product adapter calls libzernike_hip.so; the CPU tests plug in
+# an oracle-backed stand-in with the same four methods (tests/test_distributed_cpu.py)
+# ---------------------------------------------------------------------------------------------------------
+class DeviceCompute:
+    def __init__(self, plan: "_native.Plan"):
+        self.plan, self.n_poly = plan, plan.n_poly
+
+    def empty(self, shape, like):
+        import torch
+        return torch.empty(shape, dtype=torch.float64, device=like.device)
+
+    def stream(self, tensor):
+        return _current_stream_ptr(tensor)
+
+    def patches(self, patches, out_rows):
+        patch_moments_device(self.plan, patches, out=out_rows)
+
+    def frame_band(self, image, row0, n_rows, full):
+        frame_moments_device(self.plan, image, row0=row0, n_rows=n_rows, full=full)
+
+    def frame(self, image, out):
+        frame_moments_device(self.plan, image, out=out)
+
+    def maps_band(self, image, row0, n_rows, full, n_complex, folds, m_unselect, p, theta):
+        frame_maps_device(self.plan, image, n_complex, folds=folds, m_unselect=m_unselect, p=p, theta=theta,
+                          row0=row0, n_rows=n_rows, full=full)
+
+
+def _as_compute(plan_or_compute):
+    return plan_or_compute if hasattr(plan_or_compute, "frame_band") else DeviceCompute(plan_or_compute)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# sharded drivers: kernel(chunk c+1) overlaps the transfer of chunk c; every rank ends with the full result
+# ---------------------------------------------------------------------------------------------------------
+def sharded_patch_moments(plan, comm, patches_local, n_total, out=None, n_chunks=4):
+    """Batch of ``n_total`` patches split into the blocks of :func:`shard_bounds`; ``patches_local`` is this
+    rank's block ``(count, K, K)``.  Returns the full ``(n_total, n_poly)`` float64 matrix on every rank."""
+    compute = _as_compute(plan)
+    start, count, padded = shard_bounds(n_total, comm.rank, comm.world)
+    if patches_local.shape[0] != count:
+        raise ValueError(f"rank {comm.rank} owns {count} of {n_total} patches, got {patches_local.shape[0]}")
+    full = compute.empty((n_total, compute.n_poly), patches_local) if out is None else out
+    stream = compute.stream(full)
+    for c0, c1 in _chunk_bounds(padded, n_chunks):
+        lo, hi = min(c0, count), min(c1, count)
+        if hi > lo:
+            compute.patches(patches_local[lo:hi], full[start + lo:start + hi])
+        comm.allgather_rows(full, 1, n_total, compute.n_poly, padded, c0, c1 - c0, stream)
+    comm.join(stream)
+    return full
+
+
+def sharded_frame_moments(plan, comm, image, out=None, n_chunks=4):
+    """Dense transform of one frame (replicated on every rank -- it is small): rank r computes the row band
+    ``shard_bounds(H, r, world)`` in place into the full ``(n_poly, H, W)`` array, sub-band by sub-band, each
+    gathered while the next one is computed."""
+    compute = _as_compute(plan)
+    h, w = image.shape
+    start, count, padded = shard_bounds(h, comm.rank, comm.world)
+    full = compute.empty((compute.n_poly, h, w), image) if out is None else out
+    stream = compute.stream(full)
+    for c0, c1 in _chunk_bounds(padded, n_chunks):
+        lo, hi = min(c0, count), min(c1, count)
+        if hi > lo:
+            compute.frame_band(image, start + lo, hi - lo, full)
+        comm.allgather_rows(full, compute.n_poly, h, w, padded, c0, c1 - c0, stream)
+    comm.join(stream)
+    return full
+
+
+def sharded_frame_maps(plan, comm, image, n_complex, folds=(2, 3, 4, 6), m_unselect=(0, 1), p=2, theta=None,
+                       want_abs=True, n_chunks=4):
+    """configs[4]: frame -> fused symmetry maps, row bands sharded, the maps (not the moments) gathered:
+    ``len(folds) + n_complex + 1`` planes instead of ``n_poly``.  Returns ``(rot, abs, mirror)`` whole-frame
+    tensors (``None`` where not requested) on every rank."""
+    compute = _as_compute(plan)
+    h, w = image.shape
+    start, count, padded = shard_bounds(h, comm.rank, comm.world)
+    n_folds = len(folds) if folds is not None else 0
+    rot = compute.empty((n_folds, h, w), image) if n_folds else None
+    ab = compute.empty((n_complex, h, w), image) if want_abs else None
+    mir = compute.empty((h, w), image) if theta is not None else None
+    full = (rot, ab, mir)
+    stream = compute.stream(image)
+    for c0, c1 in _chunk_bounds(padded, n_chunks):
+        lo, hi = min(c0, count), min(c1, count)
+        if hi > lo:
+            compute.maps_band(image, start + lo, hi - lo, full, n_complex, folds, m_unselect, p, theta)
+        for t in full:
+            if t is not None:
+                comm.allgather_rows(t, t.numel() // (h * w), h, w, padded, c0, c1 - c0, stream)
+    comm.join(stream)
+    return full
+
+
+def sharded_frames_moments(plan, comm, frames_local, n_frames, out=None):
+    """configs[3]: a batch of ``n_frames`` frames sharded by whole frames (``frames_local``: this rank's
+    ``(count, H, W)`` block).  Frame i of every rank is transformed, then gathered while frame i+1 is
+    computed; returns the full ``(n_frames, n_poly, H, W)`` array on every rank."""
+    compute = _as_compute(plan)
+    start, count, padded = shard_bounds(n_frames, comm.rank, comm.world)
+    if frames_local.shape[0] != count:
+        raise ValueError(f"rank {comm.rank} owns {count} of {n_frames} frames, got {frames_local.shape[0]}")
+    h, w = frames_local.shape[1:]
+    full = compute.empty((n_frames, compute.n_poly, h, w), frames_local) if out is None else out
+    stream = compute.stream(full)
+    for i in range(padded):
+        if i < count:
+            compute.frame(frames_local[i], full[start + i])
+        comm.allgather_rows(full, 1, n_frames, compute.n_poly * h * w, padded, i, 1, stream)
+    comm.join(stream)
+    return full
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round-1 helpers on torch.distributed (kept for callers that already run a process group; test aid)
+# ---------------------------------------------------------------------------------------------------------
 def allgather_patch_moments(local, n_total=None, group=None, out=None):
     """All-gather equal-sized ``(padded, n_poly)`` blocks into ``(world*padded, n_poly)`` on every
     rank (one collective), trimmed to ``n_total`` rows when given."""
@@ -111,34 +373,3 @@ def allgather_frame_moments(local, height=None, group=None):
     dist.all_gather_into_tensor(slab, local.contiguous(), group=group)
     full = slab.view(world, n_poly, rows, width).permute(1, 0, 2, 3).reshape(n_poly, world * rows, width)
     return full if height is None else full[:, :height]
-
-
-def sharded_patch_moments(plan: "_native.Plan", patches, group=None):
-    """Whole-job batch transform on an initialised process group: every rank passes the SAME
-    ``(N, K, K)`` CUDA/HIP tensor (or at least its own block of it), computes the moments of its
-    contiguous block ``shard_bounds(N, rank, world)`` and receives the full ``(N, n_poly)`` matrix from
-    one all-gather.  Returns a float64 tensor on the rank's device."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    n = patches.shape[0]
-    start, count, padded = shard_bounds(n, rank, world)
-    local = torch.zeros((padded, plan.n_poly), dtype=torch.float64, device=patches.device)
-    if count:
-        patch_moments_device(plan, patches[start:start + count].contiguous(), out=local[:count])
-    return allgather_patch_moments(local, n_total=n, group=group)
-
-
-def sharded_frame_moments(plan: "_native.Plan", image, group=None):
-    """Whole-job dense transform: the frame is replicated (it is small), every rank computes the row band
-    ``shard_bounds(H, rank, world)`` and one all-gather reassembles ``(n_poly, H, W)`` on every rank."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    h, w = image.shape
-    start, count, padded = shard_bounds(h, rank, world)
-    local = torch.zeros((plan.n_poly, padded, w), dtype=torch.float64, device=image.device)
-    if count:
-        band = frame_moments_device(plan, image, row0=start, n_rows=count)
-        local[:, :count] = band
-    return allgather_frame_moments(local, height=h, group=group)

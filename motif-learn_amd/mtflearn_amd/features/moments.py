@@ -135,6 +135,18 @@ class zmoments:
     """
 
     def __init__(self, data, n, m, patch_size=None):
+        self._setup(data, n, m, patch_size, own=False)
+
+    @classmethod
+    def _adopt(cls, data, n, m, patch_size=None):
+        """Container around an array the caller hands over (results this package just produced): no copy when
+        the moment axis is already in (n, m) order.  The public constructor always copies, as the reference's
+        fancy-index permutation does (``_zmoments.py:277``), so in-place edits never reach the caller's array."""
+        self = cls.__new__(cls)
+        self._setup(data, n, m, patch_size, own=True)
+        return self
+
+    def _setup(self, data, n, m, patch_size, own):
         self.n = np.asarray(n)
         self.m = np.asarray(m)
         self.data = np.asarray(data)
@@ -149,8 +161,9 @@ class zmoments:
                 f"Data shape mismatch: expected {len(self.n)} moments but got {have}")
         order = np.lexsort((self.m, self.n))
         if not np.array_equal(order, np.arange(order.size)):
-            # already-sorted input (everything ZPs produces) keeps its buffer untouched
             self.data = np.take(self.data, order, axis=self._axis)
+        elif not own:
+            self.data = self.data.copy()
         self.n = self.n[order]
         self.m = self.m[order]
 
@@ -161,7 +174,7 @@ class zmoments:
         return 1 if self.data.ndim == 2 else 0
 
     def _like(self, data, n=None, m=None):
-        return zmoments(data=data, n=self.n if n is None else n,
+        return zmoments._adopt(data=data, n=self.n if n is None else n,
                         m=self.m if m is None else m, patch_size=self.patch_size)
 
     def _mix(self, matrix, data=None):
@@ -233,7 +246,7 @@ class zmoments:
         phase = np.exp(-1j * np.deg2rad(theta) * zc.m)
         if zc.data.ndim == 3:
             phase = phase[:, None, None]
-        return zmoments(data=zc.data * phase, n=zc.n, m=zc.m, patch_size=self.patch_size)
+        return zmoments._adopt(data=zc.data * phase, n=zc.n, m=zc.m, patch_size=self.patch_size)
 
     def _prepared(self, m_unselect, p):
         picked = self.unselect(m_unselect)

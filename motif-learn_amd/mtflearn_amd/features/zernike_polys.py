@@ -15,11 +15,19 @@ fallback -- without a HIP device ``transform`` raises ``RuntimeError``.  The bas
 on the host exactly as the reference builds it (``_zps.py:52-90``), so ``polynomials`` is
 bit-identical.
 
-Device selection: environment variable ``MTFLEARN_AMD_DEVICE`` (default 0), read at first use.
+Device selection, at first use: ``ZPs.to_device(i)`` if it was called, else the environment variable
+``MTFLEARN_AMD_DEVICE``, else ``LOCAL_RANK`` (one process per GPU under a launcher), else -- when PyTorch is
+already imported and has initialised HIP -- ``torch.cuda.current_device()``, else 0.
+
+Thread safety: a ``ZPs`` object shares one device plan (staging buffers, one stream); calls on the same object
+are serialised by a lock (the reference is stateless NumPy and needs none).  ``release()`` frees the plan's
+staging memory.  Large results are page-locked arrays out of a recycling pool (``_native.PinnedPool``).
 """
 from __future__ import annotations
 
 import os
+import sys
+import threading
 import warnings
 
 import numpy as np
@@ -74,6 +82,8 @@ class ZPs(BaseEstimator, TransformerMixin):
         self.size = size
         self.n, self.m, self.polynomials = self._generate_polynomials()
         self._plan = None
+        self._device = None
+        self._lock = threading.RLock()
 
     # ------------------------------------------------------------------ basis (host)
     def _generate_polynomials(self):
@@ -115,16 +125,47 @@ class ZPs(BaseEstimator, TransformerMixin):
         return self.fit(X).transform(X)
 
     # ------------------------------------------------------------------ device plan
+    def _pick_device(self):
+        if getattr(self, "_device", None) is not None:
+            return self._device
+        for var in ("MTFLEARN_AMD_DEVICE", "LOCAL_RANK"):
+            if os.environ.get(var, "") != "":
+                return int(os.environ[var])
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+            return int(torch.cuda.current_device())
+        return 0
+
+    def to_device(self, index):
+        """Bind this transformer to GPU ``index`` (drops a plan created on another device)."""
+        with self._lock:
+            if self._plan is not None and self._plan.device != int(index):
+                self._plan.close()
+                self._plan = None
+            self._device = int(index)
+        return self
+
     def _device_plan(self):
-        if self._plan is None:
-            device = int(os.environ.get("MTFLEARN_AMD_DEVICE", "0"))
-            self._plan = _native.Plan(self.polynomials, self.n, self.m, device=device)
-        return self._plan
+        with self._lock:
+            if self._plan is None:
+                self._plan = _native.Plan(self.polynomials, self.n, self.m, device=self._pick_device())
+            return self._plan
+
+    def release(self):
+        """Free the device staging buffers this object's calls have grown (they are re-created on demand)."""
+        with self._lock:
+            if self._plan is not None:
+                self._plan.release_staging()
 
     def __getstate__(self):
         state = dict(super().__getstate__())
         state["_plan"] = None  # device handles do not pickle / deepcopy
+        state.pop("_lock", None)
         return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._lock = threading.RLock()
 
     @staticmethod
     def _device_operand(images):
@@ -166,9 +207,9 @@ class ZPs(BaseEstimator, TransformerMixin):
         if pts.shape[0] == 0:
             return zmoments(np.empty((0, len(self.n))), self.n, self.m, patch_size=self.size)
         operand = self._device_operand(image)
-        plan = self._device_plan()
-        data = plan.transform_points(operand, pts)  # (plans without the key-point kernel gather on the device)
-        return zmoments(data=data, n=self.n, m=self.m, patch_size=self.size)
+        with self._lock:
+            data = self._device_plan().transform_points(operand, pts)  # (plans without the key-point kernel gather on the device)
+        return zmoments._adopt(data=data, n=self.n, m=self.m, patch_size=self.size)
 
     def transform_grid(self, image, step=1) -> zmoments:
         """Moments of the un-padded ``size`` x ``size`` windows taken every ``step`` pixels (extension).
@@ -238,8 +279,9 @@ class ZPs(BaseEstimator, TransformerMixin):
                  and all(int(f) == f and f > 0 for f in folds))
         out = {}
         if fused:
-            rot, ab, mir = plan.frame_maps(operand, len(complex_n), folds=folds, m_unselect=m_unselect, p=p,
-                                           theta=theta if mirror else None, want_abs=abs_moments)
+            with self._lock:
+                rot, ab, mir = plan.frame_maps(operand, len(complex_n), folds=folds, m_unselect=m_unselect, p=p,
+                                               theta=theta if mirror else None, want_abs=abs_moments)
         else:
             zm = self._transform_frame(image)
             rot = zm.rot_maps(folds, p=p, m_unselect=m_unselect) if folds else None
@@ -273,8 +315,10 @@ class ZPs(BaseEstimator, TransformerMixin):
         if images.shape[0] == 0:
             data = np.empty((0, len(self.n)), dtype=np.float64)
         else:
-            data = self._device_plan().transform_patches(self._device_operand(images))
-        return zmoments(data=data, n=self.n, m=self.m, patch_size=self.size)
+            operand = self._device_operand(images)
+            with self._lock:
+                data = self._device_plan().transform_patches(operand)
+        return zmoments._adopt(data=data, n=self.n, m=self.m, patch_size=self.size)
 
     def _transform_frame(self, image):
         height, width = image.shape
@@ -282,5 +326,7 @@ class ZPs(BaseEstimator, TransformerMixin):
             raise ValueError(
                 f"For FFT convolution, image size ({height}x{width}) must be at least "
                 f"as large as polynomial size ({self.size}x{self.size})")
-        data = self._device_plan().transform_frame(self._device_operand(image))
-        return zmoments(data=data, n=self.n, m=self.m, patch_size=self.size)
+        operand = self._device_operand(image)
+        with self._lock:
+            data = self._device_plan().transform_frame(operand)
+        return zmoments._adopt(data=data, n=self.n, m=self.m, patch_size=self.size)

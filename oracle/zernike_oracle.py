@@ -123,6 +123,22 @@ def moments_frame_direct(image: np.ndarray, basis: np.ndarray, rows=None, cols=N
     return out / unit_disk_area(size)
 
 
+def moments_frame_at(image: np.ndarray, basis: np.ndarray, rows, cols) -> np.ndarray:
+    """``moments_frame_direct`` at the PAIRED positions ``(rows[k], cols[k])`` -> ``(len(rows), n_poly)``: the same
+    zero-padded windows and the same inner products (``_zps.py:159-193`` without the FFT), the frame padded once
+    -- for spot checks on 4096 x 4096 frames."""
+    n_poly, size, _ = basis.shape
+    h, w = image.shape
+    eb = (size - 1) // 2
+    ea = size - 1 - eb
+    padded = np.zeros((h + size - 1, w + size - 1), dtype=np.float64)
+    padded[ea:ea + h, ea:ea + w] = image
+    flat_b = basis.reshape(n_poly, size * size)
+    win = np.lib.stride_tricks.sliding_window_view(padded, (size, size))
+    block = win[np.asarray(rows), np.asarray(cols)].reshape(len(rows), size * size)
+    return (block @ flat_b.T) / unit_disk_area(size)
+
+
 # --------------------------------------------------------------------------------------
 # index maps and mixing matrices  (mtflearn/features/_zmoments.py:3-235)
 # --------------------------------------------------------------------------------------

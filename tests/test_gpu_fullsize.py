@@ -1,0 +1,134 @@
+"""BASELINE configs [2] and [4] at their full 4096 x 4096 size, through the C ABI on the GPU.
+
+The oracle cannot finish 16.8 M positions, so parity at full size rests on:
+  * an independent kernel: the batch kernel on >= 10^5 strided windows equals the dense kernel there,
+  * linearity of the dense kernel on the whole frame,
+  * >= 300 oracle positions, chosen to include the zero-padded borders and the rows / columns where the
+    even-K alignment of reference ``_zps.py:165-178`` decides which pixels a window covers,
+  * row bands (the multi-GPU shards), written IN PLACE into the full array through the plane-stride entry
+    points, reassemble the one-launch result bit for bit.
+Tolerance: elementwise rtol 1e-6 (north_star) with the 1e-12 * max|Z| floor of conftest.rel_close
+(1e-11 at n_max 12, the rounding of the Legendre form there)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import rel_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _zps(n_max, size):
+    from mtflearn_amd import ZPs
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return ZPs(n_max, size)
+
+
+def _positions(H, K, rng, n_random=220):
+    """(rows, cols): random interior positions plus every combination of border / alignment coordinates."""
+    eb = (K - 1) // 2
+    ea = K - 1 - eb
+    edge = [0, 1, eb - 1, eb, ea, ea + 1, H // 2, H - 1 - ea - 1, H - 1 - ea, H - 1 - eb, H - 2, H - 1]
+    rows = list(rng.integers(0, H, n_random))
+    cols = list(rng.integers(0, H, n_random))
+    for r in edge:
+        for c in (0, ea, H // 3, H - 1 - eb, H - 1):
+            rows.append(r)
+            cols.append(c)
+    for c in edge:
+        rows.append(int(rng.integers(0, H)))
+        cols.append(c)
+    return np.array(rows), np.array(cols)
+
+
+def _oracle_at(zo, frame, z, rows, cols):
+    return zo.moments_frame_at(frame, z.polynomials, rows, cols)
+
+
+@pytest.mark.parametrize("n_max,size,step,floor", [(12, 64, 12, 1e-11), (10, 32, 12, 1e-12)])
+def test_dense_full_4096(n_max, size, step, floor):
+    """configs[2] (64-px, n_max 12 -> 12.2 GB of moments) and the moments of configs[4] (32-px, n_max 10 ->
+    8.9 GB) on the whole 4096^2 frame."""
+    import torch
+    from oracle import zernike_oracle as zo
+    from mtflearn_amd.synthetic import honeycomb_frame
+    from mtflearn_amd.distributed import frame_moments_device, patch_moments_device, shard_bounds
+    H, K = 4096, size
+    z = _zps(n_max, K)
+    plan = z._device_plan()
+    n_poly = len(z.n)
+    frame = honeycomb_frame(H, seed=1)
+    dev = torch.device("cuda:0")
+    f = torch.from_numpy(frame).to(dev)
+    zf = frame_moments_device(plan, f)                                    # (n_poly, 4096, 4096)
+    torch.cuda.synchronize()
+    scale = zf.abs().max().item()
+
+    # independent kernel: batch moments of the strided windows == dense moments at their centres
+    win = f.unfold(0, K, step).unfold(1, K, step)
+    nr, nc = win.shape[:2]
+    assert nr * nc >= 100000
+    zp = patch_moments_device(plan, win.reshape(-1, K, K).contiguous())
+    ea = K - 1 - (K - 1) // 2
+    at = zf[:, ea:ea + (nr - 1) * step + 1:step, ea:ea + (nc - 1) * step + 1:step].permute(1, 2, 0).reshape(-1, n_poly)
+    assert (zp - at).abs().max().item() <= floor * scale
+    del zp, at, win
+
+    # oracle: interior, zero-padded borders, even-K alignment rows / columns
+    rng = np.random.default_rng(11)
+    rows, cols = _positions(H, K, rng)
+    assert len(rows) >= 300
+    got = zf[:, torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev)].T.cpu().numpy()
+    rel_close(got, _oracle_at(zo, frame, z, rows, cols), atol_scale=floor)
+
+    # the shards of an 8-GPU run, written in place into one (n_poly, H, W) array, give the same bits
+    full = torch.full((n_poly, H, H), float("nan"), dtype=torch.float64, device=dev)
+    for rank in range(8):
+        start, count, _ = shard_bounds(H, rank, 8)
+        frame_moments_device(plan, f, row0=start, n_rows=count, full=full)
+    assert torch.equal(full, zf)
+    del full
+
+    # linearity on the whole frame (inputs chosen so that 2 g1 + 3 g2 is exact in float32)
+    g1 = torch.randint(0, 64, (H, H), device=dev).float() / 256
+    g2 = torch.randint(0, 64, (H, H), device=dev).float() / 256
+    frame_moments_device(plan, 2 * g1 + 3 * g2, out=zf)
+    rhs = frame_moments_device(plan, g1)
+    rhs *= 2
+    tmp = frame_moments_device(plan, g2)
+    rhs.add_(tmp, alpha=3)
+    assert (zf - rhs).abs().max().item() <= floor * zf.abs().max().item()
+
+
+def test_symmetry_maps_full_4096():
+    """configs[4] end to end: the fused maps of the whole 4096^2 frame (41 planes, 5.5 GB) against the
+    reference's tail (oracle rot_maps / to_complex / mirror_map) at >= 300 positions, and the row-band shards
+    written in place."""
+    import torch
+    from oracle import zernike_oracle as zo
+    from mtflearn_amd.synthetic import honeycomb_frame
+    from mtflearn_amd.distributed import frame_maps_device, shard_bounds
+    H, K, n_max = 4096, 32, 10
+    z = _zps(n_max, K)
+    plan = z._device_plan()
+    frame = honeycomb_frame(H, seed=1)
+    dev = torch.device("cuda:0")
+    f = torch.from_numpy(frame).to(dev)
+    theta = np.linspace(0, 2 * np.pi, 360, endpoint=False)
+    n_c = sum(k // 2 + 1 for k in range(n_max + 1))
+    rot, ab, mir = frame_maps_device(plan, f, n_c, folds=(2, 3, 4, 6), theta=theta)
+    rng = np.random.default_rng(12)
+    rows, cols = _positions(H, K, rng)
+    ref = _oracle_at(zo, frame, z, rows, cols)
+    ri, ci = torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev)
+    rel_close(rot[:, ri, ci].T.cpu().numpy(), zo.rot_maps(ref, z.n, z.m, [2, 3, 4, 6]), rtol=1e-8, atol_scale=1e-11)
+    rel_close(ab[:, ri, ci].T.cpu().numpy(), np.abs(zo.to_complex(ref, z.n, z.m)[0]), rtol=1e-8, atol_scale=1e-11)
+    rel_close(mir[ri, ci].cpu().numpy(), zo.mirror_map(ref, z.n, z.m), rtol=1e-8, atol_scale=1e-11)
+    nan = lambda *s: torch.full(s, float("nan"), dtype=torch.float64, device=dev)
+    full = (nan(4, H, H), nan(n_c, H, H), nan(H, H))
+    for rank in range(8):
+        start, count, _ = shard_bounds(H, rank, 8)
+        frame_maps_device(plan, f, n_c, folds=(2, 3, 4, 6), theta=theta, row0=start, n_rows=count, full=full)
+    assert torch.equal(full[0], rot) and torch.equal(full[1], ab) and torch.equal(full[2], mir)

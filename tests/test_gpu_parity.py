@@ -584,24 +584,25 @@ def test_row_bands_reassemble_full_frame(native):
 
 
 def test_sharded_helpers_single_rank_group(native, zo):
-    """The whole-job helpers (shard -> kernel -> one all-gather) on a world-size-1 gloo group on the GPU:
-    same code path as N ranks, checked against the oracle."""
+    """The sharded drivers on the test-aid communicator (world-size-1 gloo group) on the GPU: same driver code
+    as N ranks, checked against the oracle.  (The RCCL communicator: tests/test_gpu_runtime.py.)"""
     torch = _torch()
     import os
     import torch.distributed as dist
-    from mtflearn_amd.distributed import sharded_patch_moments, sharded_frame_moments
+    from mtflearn_amd.distributed import TorchComm, sharded_patch_moments, sharded_frame_moments
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
+        comm = TorchComm()
         z = _zps(8, 32)
         plan = z._device_plan()
         rng = np.random.default_rng(3)
         p = rng.random((333, 32, 32), dtype=np.float32)
-        got = sharded_patch_moments(plan, torch.from_numpy(p).cuda()).cpu().numpy()
+        got = sharded_patch_moments(plan, comm, torch.from_numpy(p).cuda(), 333).cpu().numpy()
         rel_close(got, zo.moments_patches(p, z.polynomials))
         img = rng.random((45, 77), dtype=np.float32)
-        gotf = sharded_frame_moments(plan, torch.from_numpy(img).cuda()).cpu().numpy()
+        gotf = sharded_frame_moments(plan, comm, torch.from_numpy(img).cuda()).cpu().numpy()
         rel_close(gotf, zo.moments_frame_direct(img, z.polynomials))
     finally:
         dist.destroy_process_group()

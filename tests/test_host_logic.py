@@ -250,7 +250,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/zernike_hip.h but not exported"
     assert sorted(_native.SYMBOLS) == declared                          # the ctypes table binds all of them
-    assert _native.load().zk_abi_version() == 1
+    assert _native.load().zk_abi_version() == 2
 
 
 def test_product_fails_loudly_without_device():
