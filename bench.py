@@ -173,6 +173,11 @@ def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    # stdout carries exactly ONE line (the JSON): whatever libraries print on fd 1 (gloo's connection banner, RCCL
+    # with NCCL_DEBUG set) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # Rehearsal knobs (a 1-GPU box cannot run RCCL between two ranks): ZK_BENCH_BACKEND=gloo with
     # ZK_BENCH_ONE_DEVICE=1 puts every rank on device 0 and runs the same drivers on the test-aid communicator.
     backend = os.environ.get("ZK_BENCH_BACKEND", "rccl")
@@ -321,8 +326,8 @@ def worker(args):
             result["cpu_baseline"] = cpu_baseline(z, frame, K)
             result["cpu_baseline_dense"] = cpu_dense_baseline(z, frame)
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
-    print(json.dumps(result))
     sys.stdout.flush()
+    os.write(json_fd, (json.dumps(result) + "\n").encode())
     if comm is not None:
         comm.barrier()
         comm.close()

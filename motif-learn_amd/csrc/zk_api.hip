@@ -240,7 +240,7 @@ extern "C" int zk_transform_patches_dev(zk_plan* p, const void* patches, int dty
   if (!patches || !out) return zk_fail(ZK_E_BADARG, "null device pointer");
   ZK_ON_PLAN_DEVICE(p);
   hipStream_t s = (hipStream_t)hip_stream;  // exactly the caller's stream; NULL is HIP's default stream
-  const int path = resolve_path(p, 0, dtype, n_patches);
+  const int path = resolve_path(p, 0, dtype, n_patches > p->job_units ? n_patches : p->job_units);
   if (path < 0) return zk_fail(ZK_E_BADARG, "the forced kernel path is not available for this plan / dtype");
   if (path == ZK_PATH_SEPARABLE) return zk_launch_sep_patches(p, patches, dtype, n_patches, out, s);
   if (path == ZK_PATH_STREAM) return zk_launch_sep_stream(p, patches, dtype, n_patches, out, s);

@@ -177,6 +177,11 @@ extern "C" int zk_transform_patches(zk_plan* p, const void* patches_host, int dt
   if (chunk > n_patches) chunk = n_patches;
   const int n_chunks = (int)((n_patches + chunk - 1) / chunk);
   auto count = [&](int c) { return n_patches - c * chunk < chunk ? n_patches - c * chunk : chunk; };
+  p->job_units = n_patches;
+  struct reset_units {
+    zk_plan* p;
+    ~reset_units() { p->job_units = 0; }
+  } reset{p};
   return run_chunks(
       p, r, n_chunks,
       [&](int c, int slot) -> int {

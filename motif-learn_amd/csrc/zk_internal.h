@@ -54,6 +54,9 @@ struct zk_plan {
   // (n_rows * W).  Set for the duration of one *_strided call (zk_api.hip) so that a row band lands inside
   // the full (planes, H, W) array -- the layout the multi-GPU gather reassembles in place.
   long long out_plane = 0;
+  // patches of the whole job while a host-buffer call feeds the batch kernels chunk by chunk: ZK_PATH_AUTO picks
+  // the kernel the job as a whole would get (same numbers whatever the chunking)
+  int64_t job_units = 0;
 
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;  // pairs: [2k] start, [2k+1] stop

@@ -26,7 +26,7 @@ def _zps(n_max, size):
         return ZPs(n_max, size)
 
 
-def _positions(H, K, rng, n_random=220):
+def _positions(H, K, rng, n_random=240):
     """(rows, cols): random interior positions plus every combination of border / alignment coordinates."""
     eb = (K - 1) // 2
     ea = K - 1 - eb

@@ -51,10 +51,14 @@ def test_host_pipeline_many_chunks_equals_one_chunk():
     plan.set_host_chunk(1 << 20)          # 1 MiB: ~235 patches -> rounded to 256 per chunk -> 20 chunks; 8-row bands
     many = run()
     plan.set_host_chunk(0)
-    for a, b in zip(one[:3], many[:3]):
-        np.testing.assert_array_equal(a, b)
+    # dense results do not depend on the cut (same kernel, one lane per output pixel): bit-identical
+    np.testing.assert_array_equal(one[1], many[1])
     for a, b in zip(one[3], many[3]):
         np.testing.assert_array_equal(a, b)
+    # batch / key-point results may come from another kernel variant at another batch size (ZK_PATH_AUTO looks at
+    # the count): equal to rounding
+    for k in (0, 2):
+        np.testing.assert_allclose(many[k], one[k], rtol=0, atol=1e-13 * np.abs(one[k]).max())
     rel_close(many[0], zo.moments_patches(patches, z.polynomials))
     rel_close(many[1], zo.moments_frame_direct(frame, z.polynomials))
     z.release()
