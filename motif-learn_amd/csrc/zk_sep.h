@@ -259,8 +259,9 @@ struct zk_sep_rows {
   // first row of a pair accumulates into SEp / SOp, the second into SEm / SOm, and pair_combine() turns
   // them into the sum / difference the row_end() step expects:
   //   SEp <- X1 + X2 (even b),  SEm <- X1 - X2 (odd b),  same for SO.
-  template <bool FIRST>
-  __device__ __forceinline__ void row_pixel(double a, double b, const ZK_CONST double* px) {
+  // (px: a table row in the constant address space, or its values already in registers)
+  template <bool FIRST, typename PX>
+  __device__ __forceinline__ void row_pixel(double a, double b, const PX& px) {
     const double s = a + b, d = a - b;
 #pragma unroll
     for (int i = 0; i < S::NE; ++i) {
@@ -271,6 +272,23 @@ struct zk_sep_rows {
     for (int i = 0; i < S::NO; ++i) {
       if (FIRST) SOp[i] = __builtin_fma(d, px[2 * i + 1], SOp[i]);
       else SOm[i] = __builtin_fma(d, px[2 * i + 1], SOm[i]);
+    }
+  }
+  // the same with P_0 = 1 implicit: p1[a - 1] = P_a(x_c), a = 1 .. NMAX (even patch sizes: no half-weight column)
+  template <bool FIRST, typename PX>
+  __device__ __forceinline__ void row_pixel_p0(double a, double b, const PX& p1) {
+    const double s = a + b, d = a - b;
+    if (FIRST) SEp[0] += s;
+    else SEm[0] += s;
+#pragma unroll
+    for (int i = 1; i < S::NE; ++i) {
+      if (FIRST) SEp[i] = __builtin_fma(s, p1[2 * i - 1], SEp[i]);
+      else SEm[i] = __builtin_fma(s, p1[2 * i - 1], SEm[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < S::NO; ++i) {
+      if (FIRST) SOp[i] = __builtin_fma(d, p1[2 * i], SOp[i]);
+      else SOm[i] = __builtin_fma(d, p1[2 * i], SOm[i]);
     }
   }
   __device__ __forceinline__ void pair_combine() {

@@ -71,6 +71,18 @@ namespace {
 #ifndef ZK_BATCH_2W
 #define ZK_BATCH_2W 10  // largest kernel n_max compiled for two waves per SIMD
 #endif
+// LDS slabs (units in flight) per wave.  Kernels that fit two waves per SIMD run 8 waves per CU with one 16-KiB
+// slab each (128 KiB): the other wave of the SIMD computes while this one waits for its DMA.  Above
+// ZK_BATCH_2W a SIMD holds ONE wave, which with one slab alternates between waiting for a unit (HBM latency,
+// ~2-3 us under load) and consuming it (~1 us at n_max 12) -- 4.8 TB/s at (64, 12).  Two slabs per wave (4 waves x
+// 32 KiB = 128 KiB) keep the next unit's DMA in flight during the whole of the current unit's arithmetic.
+#ifndef ZK_BATCH_DEPTH_1W
+#define ZK_BATCH_DEPTH_1W 2
+#endif
+#ifndef ZK_BATCH_PIPE
+#define ZK_BATCH_PIPE 1  // wide units: software-pipelined scalar loads (see quarter())
+#endif
+#define ZK_BATCH_DEPTH(NMAX, MASK) (((NMAX) <= ZK_BATCH_2W || (MASK) != 15) ? 1 : ZK_BATCH_DEPTH_1W)
 
 // MASK: the parity classes this launch computes -- all of them (15), or one class per launch for
 // n_max > 16 (zk_sep.h); a class pass writes its moments as planes of a scratch matrix [column][patch]
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
     const TIN* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
     int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp, const int32_t* __restrict__ row_starts,
-    int n_row_starts) {
+    int n_row_starts, const double* __restrict__ pfull) {
   using S = zk_sep_set<NMAX>;
   constexpr int PXG = 16 / sizeof(TIN);  // pixels per 16-B granule: 4 (float32) or 2 (float64)
   typedef TIN gran_t __attribute__((ext_vector_type(PXG)));
@@ -90,11 +102,12 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
   // nt only where a run is a whole 128-B line: 64-B runs share their line with another unit of the same
   // row, which must still find it in L2 (default policy: 3.70 -> 2.14 ms at K=16, 8.9 -> 6.0 ms at K=48)
   constexpr int DMA_AUX = RUN == 8 ? ZK_DMA_AUX : 0;
-  __shared__ __attribute__((aligned(16))) float lds[4 * 4096];  // 16 KiB per wave
+  constexpr int DEPTH = ZK_BATCH_DEPTH(NMAX, MASK);
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // DEPTH slabs of 16 KiB per wave
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* const wl = lds + wave * 4096;
+  float* const wl = lds + wave * (4096 * DEPTH);
   const long long patch0 = ((long long)blockIdx.x * 4 + wave) * 64;
   if (patch0 >= n_patches) return;  // wave-uniform; the kernel has no workgroup barrier
   const long long left = n_patches - patch0;
@@ -114,14 +127,14 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
     poff[pg] = pi * patch_bytes + g * 16;
   }
   const ZK_CONST int32_t* utab = zk_const((const int32_t*)units);  // 8 ints per unit
-  auto issue = [&](int u) {
+  auto issue = [&](int u, float* slab) {  // 16 DMA instructions: one unit into one slab
 #pragma unroll
     for (int rho = 0; rho < NRUN; ++rho) {
       const int ro = utab[8 * u + rho];
 #pragma unroll
       for (int pg = 0; pg < RUN; ++pg) {
         __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(wbase + (poff[pg] + ro)),
-                                         ZK_LDS_PTR(wl + (rho * RUN + pg) * 256), 16, 0, DMA_AUX);
+                                         ZK_LDS_PTR(slab + (rho * RUN + pg) * 256), 16, 0, DMA_AUX);
       }
     }
   };
@@ -134,6 +147,7 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
   zk_sep_acc<NMAX, MASK> acc;
   acc.clear_all();
   const ZK_CONST double* px = zk_const(xq);
+  [[maybe_unused]] const ZK_CONST double* p1 = zk_const(pfull);
 
   // first unit of this wave (see ZK_ROTATE): the start of some row pair; the loop visits off, off+1, ...,
   // wrapping around, so the units of a row stay consecutive
@@ -142,18 +156,24 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
                       : 0;
   auto unit_at = [&](int k) { return k + off < n_units ? k + off : k + off - n_units; };
 #if ZK_ABLATE != 2
-  issue(unit_at(0));
+  issue(unit_at(0), wl);
+  if constexpr (DEPTH == 2)
+    if (n_units > 1) issue(unit_at(1), wl + 4096);
 #endif
   for (int k = 0; k < n_units; ++k) {
     const int u = unit_at(k);
     const int c0 = utab[8 * u + 4], cmin = utab[8 * u + 5], r = utab[8 * u + 6];
     const int rend = utab[8 * u + 7] & 1, cmax = utab[8 * u + 7] >> 8;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of unit u has landed
+    float* const ws = DEPTH == 2 ? wl + (k & 1) * 4096 : wl;  // wave-uniform: the slab unit k landed in
+    // this wave's DMA of unit u has landed (loads complete in order: with a second unit in flight, all but its
+    // 16 instructions)
+    if (DEPTH == 2 && k + 1 < n_units) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // The unit is consumed in two halves of 8 quadrant pixels so that only 32 staging VGPRs are live:
     // the outer half first (quadrant columns c0..c0+7, often entirely outside the disk and then not even
     // read), then the inner half; the slab is re-armed as soon as the inner half is in registers.
     auto lds_granule = [&](int rho, int g) -> gran_t {
-      return *(const gran_t*)(wl + rho * 64 * RUN * 4 + rd[g]);
+      return *(const gran_t*)(ws + rho * 64 * RUN * 4 + rd[g]);
     };
     auto half = [&](int q0, bool rearm) {  // quadrant granules q0, q0+1 of both rows and their mirrors
       gran_t A[2], B[2], C[2], D[2];      // A: (r, q)  B: (r, mirror of q)  C, D: same for row K-1-r
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
       if (rearm) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // unit is in VGPRs: the slab may be re-armed
 #if ZK_ABLATE != 2
-        if (k + 1 < n_units) issue(unit_at(k + 1));
+        if (k + DEPTH < n_units) issue(unit_at(k + DEPTH), ws);
 #endif
       }
 #if ZK_ABLATE == 1
@@ -197,6 +217,19 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
     // wide units: 8 quadrant columns (2 granules of the line + 2 of its mirror line) of a single row
     auto quarter = [&](int q0, bool rearm, auto first_row) {
       gran_t A[2], B[2];
+#if ZK_BATCH_PIPE
+      // The Legendre row of pixel c+1 is fetched (scalar loads) while pixel c is being accumulated: with one
+      // wave per SIMD nothing else hides the scalar-cache latency, and a load - wait - use sequence per pixel cost
+      // 40 % of the wave's time (profiles/r02_sq_counters.txt).  The pixels of a quarter run branch-free
+      // (columns left of the disk contribute zeros) so that the loads can be placed ahead of their use.
+      // Table: the stream kernel's P_1 .. P_NMAX rows (P_0 = 1 needs no operand; wide units exist for even patch
+      // sizes only, where no column carries a half weight) -- at n_max 12 a row is 24 dwords, two aligned loads.
+      constexpr int SROW = ZK_STREAM_ROW(NMAX);
+      double Pn[NMAX];
+      const ZK_CONST double* prow = p1 + (c0 + PXG * q0) * SROW;
+#pragma unroll
+      for (int t = 0; t < NMAX; ++t) Pn[t] = prow[t];
+#endif
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         A[i] = lds_granule(0, q0 + i);
@@ -205,7 +238,7 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
       if (rearm) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if ZK_ABLATE != 2
-        if (k + 1 < n_units) issue(unit_at(k + 1));
+        if (k + DEPTH < n_units) issue(unit_at(k + DEPTH), ws);
 #endif
       }
 #if ZK_ABLATE == 1
@@ -213,6 +246,31 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
       for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(A[i]), "v"(B[i]));
       if (false)
 #endif
+#if ZK_BATCH_PIPE
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < PXG; ++e) {
+          const int c = c0 + PXG * (q0 + i) + e;
+          // scalar loads return out of order, so the only wait there is, lgkmcnt(0), also waits for whatever was
+          // issued last: wait for this pixel's row FIRST, then put the next row's loads in flight
+          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+          __builtin_amdgcn_sched_barrier(0);
+          double Pc[NMAX];
+#pragma unroll
+          for (int t = 0; t < NMAX; ++t) Pc[t] = Pn[t];
+          if (i * PXG + e + 1 < 2 * PXG) {
+            prow += SROW;
+#pragma unroll
+            for (int t = 0; t < NMAX; ++t) Pn[t] = prow[t];
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the next row's loads above this pixel's arithmetic
+          const bool in = c >= cmin;          // wave-uniform: quadrant pixel inside the disk
+          const TIN av = in ? A[i][e] : (TIN)0, bv = in ? B[i][PXG - 1 - e] : (TIN)0;
+          acc.template row_pixel_p0<decltype(first_row)::value>((double)av, (double)bv, Pc);
+        }
+      }
+#else
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -223,6 +281,7 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
                                                                px + c * ZK_SEP_ROW);
         }
       }
+#endif
     };
     if constexpr (WIDE) {
       const bool second = (utab[8 * u + 7] >> 1) & 1;
@@ -289,11 +348,16 @@ int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
   if (blocks > 0x7fffffffLL) return zk_fail(ZK_E_BADARG, "too many patches for one launch");
   int ppp = 64;
   while (ppp * p->n_poly > 2048) ppp >>= 1;
+  auto kern = zk_patch_sep_kernel<NMAX, RUN, TIN, WIDE, MASK>;
+  const size_t lds = (size_t)4 * ZK_BATCH_DEPTH(NMAX, MASK) * 16384;
+  if (lds > 64 * 1024)
+    ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int rc = zk_prof_begin(p, s);
   if (rc) return rc;
-  hipLaunchKernelGGL((zk_patch_sep_kernel<NMAX, RUN, TIN, WIDE, MASK>), dim3((unsigned)blocks), dim3(256), 0, s, (const TIN*)in,
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, (const TIN*)in,
                      out, bt.d_units, t->d_xq, t->d_T, t->d_colmap, bt.n_units, p->n_poly, (long long)n_patches,
-                     p->size * p->size * (int)sizeof(TIN), ppp, bt.d_row_starts, ZK_ROTATE ? bt.n_row_starts : 0);
+                     p->size * p->size * (int)sizeof(TIN), ppp, bt.d_row_starts, ZK_ROTATE ? bt.n_row_starts : 0,
+                     t->d_pfull);
   ZK_HIP(hipGetLastError());
   return zk_prof_end(p, s);
 }
