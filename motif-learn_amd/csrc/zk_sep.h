@@ -240,8 +240,10 @@ struct zk_sep_rows {
 #pragma unroll
     for (int i = 0; i < S::NO; ++i) SOp[i] = SOm[i] = 0.0;
   }
-  // one quadrant pixel: a=(r,c) b=(r,c') c=(r',c) d=(r',c'); px = P_*(x_c) row of the x table
-  __device__ __forceinline__ void pixel(double a, double b, double c, double d, const ZK_CONST double* px) {
+  // one quadrant pixel: a=(r,c) b=(r,c') c=(r',c) d=(r',c'); px = P_*(x_c) row of the x table (a pointer into the
+  // constant address space, or the row's values already in registers)
+  template <typename PX>
+  __device__ __forceinline__ void pixel(double a, double b, double c, double d, const PX& px) {
     const double s1 = a + b, d1 = a - b, s2 = c + d, d2 = c - d;
     const double ee = s1 + s2, oe = d1 + d2, eo = s1 - s2, oo = d1 - d2;
 #pragma unroll
@@ -465,6 +467,18 @@ __device__ __forceinline__ void zk_batch_store_rows(const double (&z)[NP], const
 #ifndef ZK_ROW_PAIR_UNROLL4
 #define ZK_ROW_PAIR_UNROLL4 1  // (-1 % at (32, 8), -5 % at (64, 12) per dense frame)
 #endif
+// Software-pipelined form (default).  Scalar loads return out of order, so the only wait the ISA offers for them
+// is lgkmcnt(0) -- which also waits for whatever was issued last.  Left to the compiler the loop became
+// load - wait - a few FMAs - load - wait per pixel (two exposed scalar-cache latencies per pixel, VALU busy 61-80 % at
+// two waves per SIMD, profiles/r02_sq_counters.txt).  Here every step first waits for ITS operands (fetched during
+// the previous step), then puts the next pixel's four LDS reads and its Legendre row in flight, then does its
+// arithmetic.  The last step prefetches one pixel past the row (LDS tile and table have the room).
+#ifndef ZK_ROW_PAIR_PIPE
+#define ZK_ROW_PAIR_PIPE 1
+#endif
+#define ZK_LGKM_WAIT()                     \
+  __builtin_amdgcn_s_waitcnt(0xC07F);      \
+  __builtin_amdgcn_sched_barrier(0)
 template <int NMAX, int MASK>
 __device__ __forceinline__ void zk_sep_row_pair(zk_sep_acc<NMAX, MASK>& acc, const double* __restrict__ top,
                                                 const double* __restrict__ bot, int cmin, int Q, int K,
@@ -475,6 +489,50 @@ __device__ __forceinline__ void zk_sep_row_pair(zk_sep_acc<NMAX, MASK>& acc, con
   const double* bb = bot + (K - 1 - cmin);
   const ZK_CONST double* pr = px + cmin * ZK_SEP_ROW;
   int c = cmin;
+  // (the n_max 11-12 instances are register-capped at 256 for two waves per SIMD and already spill: the extra live
+  //  row costs them more than the waits did -- 2048^2 frame: (32, 12) 2.03 -> 2.50 ms, (64, 12) 5.17 -> 5.79)
+  if constexpr (ZK_ROW_PAIR_PIPE && !(NMAX == 12 && MASK == 15)) {
+  constexpr int NA = NMAX + 1;
+  double an = tf[0], bn = tb[0], cn = bf[0], dn = bb[0], Pn[NA];
+#pragma unroll
+  for (int t = 0; t < NA; ++t) Pn[t] = pr[t];
+#define ZK_PIPE_STEP(NEXT)                                                         \
+  {                                                                                \
+    ZK_LGKM_WAIT();                                                                \
+    const double a_ = an, b_ = bn, c_ = cn, d_ = dn;                               \
+    double Pc[NA];                                                                 \
+    _Pragma("unroll") for (int t = 0; t < NA; ++t) Pc[t] = Pn[t];                  \
+    an = tf[NEXT];                                                                 \
+    bn = tb[-(NEXT)];                                                              \
+    cn = bf[NEXT];                                                                 \
+    dn = bb[-(NEXT)];                                                              \
+    _Pragma("unroll") for (int t = 0; t < NA; ++t) Pn[t] = pr[(NEXT)*ZK_SEP_ROW + t]; \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    acc.pixel(a_, b_, c_, d_, Pc);                                                 \
+  }
+  for (; c + 3 < Q; c += 4) {
+    ZK_PIPE_STEP(1)
+    ZK_PIPE_STEP(2)
+    ZK_PIPE_STEP(3)
+    ZK_PIPE_STEP(4)
+    tf += 4;
+    tb -= 4;
+    bf += 4;
+    bb -= 4;
+    pr += 4 * ZK_SEP_ROW;
+  }
+  for (; c < Q; ++c) {
+    ZK_PIPE_STEP(1)
+    tf += 1;
+    tb -= 1;
+    bf += 1;
+    bb -= 1;
+    pr += ZK_SEP_ROW;
+  }
+#undef ZK_PIPE_STEP
+  ZK_LGKM_WAIT();  // the prefetch past the row has landed before anything reuses those registers
+  return;
+  }
 #if ZK_ROW_PAIR_UNROLL4
   for (; c + 3 < Q; c += 4) {  // four pixels per pointer update (the integer adds cost v_fma_f64 issue slots)
     acc.pixel(tf[0], tb[0], bf[0], bb[0], pr);

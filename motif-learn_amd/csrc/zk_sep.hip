@@ -175,7 +175,7 @@ int zk_sep_build(zk_plan* p, const double* basis) {
   t->np_kernel = npk;
   t->Q = Q;
   t->tile_pitch = K + 63;
-  std::vector<double> xq((size_t)Q * ZK_SEP_ROW, 0.0);
+  std::vector<double> xq((size_t)(Q + 1) * ZK_SEP_ROW, 0.0);  // + one zero row: the pipelined loops prefetch one row ahead
   for (int c = 0; c < Q; ++c) {
     const double w = (c == K - 1 - c) ? 0.5 : 1.0;
     for (int a = 0; a < D; ++a) xq[(size_t)c * ZK_SEP_ROW + a] = (double)(P[(size_t)c * D + a] * (ld)w);

@@ -48,7 +48,7 @@ struct zk_maps_params {
   int normalize;       // 1: p = 2, 0: p = None
   int n_theta;
   int plan_nmax;       // moments with n > plan_nmax are padding of the kernel set
-  int theta_sym;       // 1: theta is the uniform grid 2 pi k / n_theta with n_theta % 4 == 0 (see below)
+  int theta_sym;       // theta is the uniform grid 2 pi k / n_theta with 1: n_theta % 4 == 0, 2: n_theta % 8 == 0 (see below)
 };
 
 namespace {
@@ -120,7 +120,72 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
     const ZK_CONST double* cs = wtab + ZK_MAX_FOLDS * ZK_SEP_ROW;
     double best = -__builtin_inf();
     auto take = [&](double s) { best = s > best || s != s ? s : best; };  // NaN propagates like numpy.max
-    if (prm.theta_sym) {
+    if (prm.theta_sym == 2) {
+      // Uniform full-circle grid with n_theta % 8 == 0.  theta, pi - theta, pi + theta, 2 pi - theta AND the same four
+      // reflections of pi/2 - theta are all grid points, and with c_m = cos m theta, s_m = sin m theta
+      //   m = 0 (mod 4): cos m(pi/2 - t) =  c_m, sin =  -s_m        m = 1: cos =  s_m, sin =  c_m
+      //   m = 2        : cos              = -c_m, sin =   s_m        m = 3: cos = -s_m, sin = -c_m
+      // so ONE table row (angle index 0 .. n_theta/8) yields eight scores: the even-m products are shared outright,
+      // the odd m need two extra products each.  46 rows of 2 NMAX doubles instead of 91 at 360 angles: half the
+      // scalar-cache footprint (7.4 KB at n_max 10 -- the 14.6-KB quarter table, next to the pixel loop's own
+      // tables, missed the 16-KB cache: ~800 cycles per row and wave) and 3/4 of the FMAs.
+      // The table holds only (cos theta, sin theta) per row; cos m theta / sin m theta come from the three-term
+      // recurrence x_{m+1} = 2 cos(theta) x_m - x_{m-1} on the VALU (lane-uniform values, 2 FMAs per m; error
+      // ~m^2 ulp, 1e-13 at m = 24).  A full [angle][2 NMAX] table kept missing the scalar cache (~500 cycles
+      // per half row and wave even at 7.4 KB, next to the pixel loop's own tables); this one is 0.7 KB and one
+      // scalar load feeds four rows.  The host pads it to a multiple of four rows by repeating the last row.
+      const ZK_CONST double* tr = cs;
+      double best8 = -__builtin_inf();
+      const int rows4 = (prm.n_theta / 8 + 4) & ~3;
+      for (int i0 = 0; i0 < rows4; i0 += 4) {
+        double cs4[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cs4[t] = tr[2 * i0 + t];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // sums over m = r (mod 4): C c (k*), S s (l*), and for odd m the cross products C s (x*), S c (y*)
+          double k0 = 0.0, k1 = 0.0, k2 = 0.0, k3 = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+          double x1 = 0.0, x3 = 0.0, y1 = 0.0, y3 = 0.0;
+          const double c1 = cs4[2 * j], s1 = cs4[2 * j + 1], two_c1 = c1 + c1;
+          double cp_ = 1.0, sp_ = 0.0, c = c1, sn = s1;  // (cos, sin) of (m - 1) theta and m theta
+#pragma unroll
+          for (int m = 1; m <= NMAX; ++m) {  // m = 0 is always unselected (C_0 = S_0 = 0)
+            if ((m & 3) == 0) k0 = __builtin_fma(Cm[m], c, k0), l0 = __builtin_fma(Sm[m], sn, l0);
+            if ((m & 3) == 1)
+              k1 = __builtin_fma(Cm[m], c, k1), l1 = __builtin_fma(Sm[m], sn, l1), x1 = __builtin_fma(Cm[m], sn, x1),
+              y1 = __builtin_fma(Sm[m], c, y1);
+            if ((m & 3) == 2) k2 = __builtin_fma(Cm[m], c, k2), l2 = __builtin_fma(Sm[m], sn, l2);
+            if ((m & 3) == 3)
+              k3 = __builtin_fma(Cm[m], c, k3), l3 = __builtin_fma(Sm[m], sn, l3), x3 = __builtin_fma(Cm[m], sn, x3),
+              y3 = __builtin_fma(Sm[m], c, y3);
+            if (m < NMAX) {
+              const double cn_ = __builtin_fma(two_c1, c, -cp_), sn_ = __builtin_fma(two_c1, sn, -sp_);
+              cp_ = c;
+              sp_ = sn;
+              c = cn_;
+              sn = sn_;
+            }
+          }
+          // the four reflections of an angle t: scores cp +- sp (t, 2 pi - t) and cn -+ sm (pi - t, pi + t); the larger
+          // of each pair is cp + |sp| resp. cn + |sm|, bit for bit
+          auto four = [&](double ce, double co, double se, double so) {
+            const double cp = ce + co, cn = ce - co, sp = se + so, sm = se - so;
+            best8 = __builtin_fmax(best8, cp + __builtin_fabs(sp));
+            best8 = __builtin_fmax(best8, cn + __builtin_fabs(sm));
+          };
+          four(k0 + k2, k1 + k3, l0 + l2, l1 + l3);  // t = theta
+          four(k0 - k2, x1 - x3, l2 - l0, y1 - y3);  // t = pi/2 - theta
+        }
+      }
+      // v_max_f64 ignores NaN operands where numpy.max propagates them: every score is a combination of ALL the
+      // selected C_m / S_m with non-zero coefficients, so the result is NaN exactly when one of them is (non-finite
+      // moments -- inf pixels, or 0/0 from the normalisation -- give NaN here, as they do in NumPy whenever a NaN
+      // score exists).
+      double poison = 0.0;
+#pragma unroll
+      for (int m = 1; m <= NMAX; ++m) poison = __builtin_fma(Cm[m], 0.0, __builtin_fma(Sm[m], 0.0, poison));
+      best = poison != poison ? poison : best8;
+    } else if (prm.theta_sym) {
       // Uniform full-circle grid: theta, pi - theta, pi + theta and 2 pi - theta are all grid points and
       //   cos m(pi -+ t) = (-1)^m cos mt,  sin m(pi - t) = -(-1)^m sin mt,  sin m(pi + t) = (-1)^m sin mt,
       // so the first quarter of the grid (n_theta/4 + 1 rows) yields all n_theta scores.
@@ -369,7 +434,8 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
   }
   if (!(prm.unselect_mask & 1)) return zk_fail(ZK_E_BADARG, "m=0 must be included in m_unselect.");
   // device table: fold weights, then the trig rows (see the kernel)
-  std::vector<double> tab((size_t)ZK_MAX_FOLDS * ZK_SEP_ROW + (size_t)(prm.n_theta > 0 ? n_theta : 0) * 2 * knm + 16, 0.0);
+  // (+ one spare row of zeros after the angles: the pipelined mirror scan prefetches one row ahead)
+  std::vector<double> tab((size_t)ZK_MAX_FOLDS * ZK_SEP_ROW + (size_t)(prm.n_theta > 0 ? n_theta + 1 : 0) * 2 * knm + 16, 0.0);
   for (int f = 0; f < prm.n_folds; ++f) {
     const int fold = folds[f];
     if (fold <= 0) return zk_fail(ZK_E_BADARG, "folds must be positive");
@@ -388,7 +454,20 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
     prm.theta_sym = n_theta % 4 == 0;
     for (int i = 0; i < n_theta && prm.theta_sym; ++i)
       prm.theta_sym = fabs(theta[i] - 2.0 * M_PI * (double)i / (double)n_theta) <= 1e-12;
+    if (prm.theta_sym && n_theta % 8 == 0) prm.theta_sym = 2;  // eighth-grid scan
     double* tr = tab.data() + (size_t)ZK_MAX_FOLDS * ZK_SEP_ROW;
+    if (prm.theta_sym == 2) {
+      // (cos theta_i, sin theta_i) for i = 0 .. n_theta/8, padded to a multiple of four rows with the last row
+      const int last = n_theta / 8, rows4 = (last + 4) & ~3;
+      tab.resize((size_t)ZK_MAX_FOLDS * ZK_SEP_ROW + 2 * (size_t)rows4 + 16);
+      tr = tab.data() + (size_t)ZK_MAX_FOLDS * ZK_SEP_ROW;
+      for (int i = 0; i < rows4; ++i) {
+        const int k = i < last ? i : last;
+        tr[2 * i] = cos(theta[k]);
+        tr[2 * i + 1] = sin(theta[k]);
+      }
+      for (size_t z = 2 * (size_t)rows4; z < 2 * (size_t)rows4 + 16; ++z) tr[z] = 0.0;
+    } else
     for (int i = 0; i < n_theta; ++i)
       for (int m = 0; m <= knm; ++m) {
         if (m == 0) continue;  // m = 0 is always unselected

@@ -73,14 +73,21 @@ def stream_flops_per_unit(basis0, n_max):
 
 
 def maps_tail_flops(n_max, n_folds, n_theta, theta_sym=True, want_abs=True):
-    """``zk_maps_tail``: per complex moment 10 operations (+ a square root when |Z| is written), the unselect /
-    norm pass, ``n_folds`` weighted sums over |m|, and the mirror scan (a quarter of a uniform angle grid: per row
-    4 n_max FMAs' worth of multiply-adds, 12 adds / selects)."""
+    """``zk_maps_tail`` (FMA = 2, add / max / sqrt = 1): per complex moment 10 operations (+ a square root when |Z|
+    is written), the unselect / norm pass, ``n_folds`` weighted sums over |m|, and the mirror scan.  On a uniform
+    angle grid with n_theta % 8 == 0 the scan visits n_theta/8 + 1 angles (executed: rounded up to a multiple of 4);
+    per angle 2 (n_max - 1) FMAs of the cos / sin recurrence, 2 FMAs per even m and 4 per odd m, 8 + 8 adds and 4
+    add-max pairs for its eight scores; otherwise 2 n_max FMAs and one select per angle."""
     nc = n_complex(n_max)
     flops = nc * (10 + (1 if want_abs else 0)) + 4 * (n_max + 1) + n_folds * (2 * (n_max + 1) + 1)
     if n_theta:
-        rows = n_theta // 4 + 1 if theta_sym else n_theta
-        flops += rows * (4 * n_max + (12 if theta_sym else 1))
+        if theta_sym and n_theta % 8 == 0:
+            rows = (n_theta // 8 + 4) & ~3
+            n_odd = (n_max + 1) // 2
+            fmas = 2 * (n_max - 1) + 2 * (n_max - n_odd) + 4 * n_odd
+            flops += rows * (2 * fmas + 1 + 8 + 8 + 8) + 4 * n_max
+        else:
+            flops += n_theta * (4 * n_max + 1)
     return flops
 
 
