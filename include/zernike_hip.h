@@ -43,6 +43,7 @@ extern "C" {
 #define ZK_E_NODEVICE (-10002)
 #define ZK_E_NOMEM    (-10003)
 #define ZK_E_COMM     (-10004)  /* RCCL unavailable, rendezvous failed or a collective returned an error */
+#define ZK_E_FFT      (-10005)  /* hipFFT unavailable or a transform failed */
 
 /* kernel selection, for tests and A/B measurements (default ZK_PATH_AUTO = best available) */
 #define ZK_PATH_AUTO      0
@@ -243,6 +244,36 @@ int zk_allgather_rows(zk_comm* comm, double* full_dev, int64_t n_planes, int64_t
 int zk_comm_join(zk_comm* comm, void* hip_stream);
 /* Blocking all-gather of a few host bytes per rank (timings, checksums; doubles as a barrier). */
 int zk_comm_allgather_host(zk_comm* comm, const void* send_host, void* recv_host, int64_t bytes_per_rank);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Parameter pickers: the device side of the two reference routines that choose (size, n_max) for ZPs
+ * (SURVEY 8f rank 3).  Host buffers in, host buffers out, blocking; no plan involved.  The FFTs are hipFFT's
+ * (bound at run time: the library loads without it); the reference uses scipy / numpy FFTs at the same places.
+ *
+ *   zk_autocorr_mean  <- the loop of estimate_patch_size (features/_patch_size.py:268-279): for each window
+ *                        image[y:y+window, x:x+window] (origins as (y, x) pairs), standardise_image (zero mean, unit
+ *                        population std; a constant window fails with the reference's message), then
+ *                        scipy.signal.correlate(p, p, mode='same', method='fft'); out = mean over the windows,
+ *                        (window, window) float64, zero lag at [window/2, window/2].
+ *   zk_polar_profile  <- radial_profile (features/_patch_size.py:48-100): skimage.transform.warp_polar(data,
+ *                        center=(h/2, w/2), scaling='linear') aggregated over its 360 angles (method 0 mean, 1 max,
+ *                        2 sum) -> (batch, zk_polar_radii(h, w)) float64.  scikit-image is not available in the
+ *                        build image: the resampling restates its published algorithm (see zk_pickers.hip).
+ *   zk_power_spectra  <- _get_cumulative_energy up to the radial profile (features/_estimate_n_max.py:42-65):
+ *                        |fftshift(fft2(patch * outer(w, w)))|^2 for every window; window_1d may be NULL.
+ *   zk_denoise_fft    <- denoise_fft (denoise/_denoise_fft.py:4-47): keep the ceil(p H W) Fourier coefficients of
+ *                        largest power (exact selection; among coefficients that tie at the cut-off an arbitrary
+ *                        subset survives, as with numpy.argpartition), inverse transform, real part.
+ * ------------------------------------------------------------------------------------------------------ */
+int zk_autocorr_mean(int device, const void* image_host, int dtype, int64_t height, int64_t width, int64_t window,
+                     const int32_t* origins_yx, int n_windows, int standardize, double* out_host);
+int64_t zk_polar_radii(int64_t h, int64_t w);
+int zk_polar_profile(int device, const double* data_host, int64_t batch, int64_t h, int64_t w, int64_t center_row,
+                     int64_t center_col /* negative: (h/2, w/2) */, int method, double* out_host);
+int zk_power_spectra(int device, const void* image_host, int dtype, int64_t height, int64_t width, int64_t size,
+                     const int32_t* origins_yx, int n_windows, const double* window_1d, double* out_host);
+int zk_denoise_fft(int device, const void* image_host, int dtype, int64_t height, int64_t width, double p,
+                   double* out_host);
 
 /* Device memory for callers that have no allocator of their own (a NumPy / C user of the *_dev entry points). */
 int zk_device_malloc(int device, int64_t bytes, void** out_dev);

@@ -69,6 +69,14 @@ SYMBOLS = {
     "zk_allgather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "zk_comm_join": (c_int, [c_void_p, c_void_p]),
     "zk_comm_allgather_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    "zk_autocorr_mean": (c_int, [c_int, c_void_p, c_int, c_int64, c_int64, c_int64, POINTER(c_int32), c_int, c_int,
+                                 POINTER(c_double)]),
+    "zk_polar_radii": (c_int64, [c_int64, c_int64]),
+    "zk_polar_profile": (c_int, [c_int, POINTER(c_double), c_int64, c_int64, c_int64, c_int64, c_int64, c_int,
+                                 POINTER(c_double)]),
+    "zk_power_spectra": (c_int, [c_int, c_void_p, c_int, c_int64, c_int64, c_int64, POINTER(c_int32), c_int,
+                                 POINTER(c_double), POINTER(c_double)]),
+    "zk_denoise_fft": (c_int, [c_int, c_void_p, c_int, c_int64, c_int64, c_double, POINTER(c_double)]),
     "zk_device_malloc": (c_int, [c_int, c_int64, POINTER(c_void_p)]),
     "zk_device_free": (c_int, [c_int, c_void_p]),
     "zk_device_copy": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int]),

@@ -1,0 +1,123 @@
+"""Parameter pickers on the GPU, through the C ABI: device results against goldens captured from the
+reference (autocorrelation, denoise_fft) and against the CPU oracle (polar resampling, power spectra, and the two
+end-to-end routines under the same np.random seed).  Tolerance: arrays 1e-9 of their maximum (float64 FFTs of
+different libraries); integer results (peak radius, n_max) exactly."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg():
+    with np.load(os.path.join(ROOT, "tests", "golden", "pickers_golden.npz")) as f:
+        return {k: f[k] for k in f.files}
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pickers_oracle
+    return pickers_oracle
+
+
+@pytest.fixture(scope="module")
+def pk():
+    from mtflearn_amd.features import pickers
+    return pickers
+
+
+def close(got, ref, tol=1e-9):
+    np.testing.assert_allclose(got, ref, rtol=0, atol=tol * np.abs(ref).max())
+
+
+F32_TOL = 1e-6   # float32 inputs: the reference's scipy / numpy FFTs run in single precision there (its goldens carry
+                 # ~1e-7 of their maximum in rounding noise); the device path computes in float64
+
+
+def test_autocorrelation_golden(pg, pk):
+    close(pk.autocorrelation(pg["win_64"]), pg["autocorr_64"], F32_TOL)
+    close(pk.autocorrelation(pg["win_64"].astype(np.float64)), pg["autocorr_64"], F32_TOL)
+    close(pk.autocorrelation(pg["win_64"], standardize=False), pg["autocorr_64_raw"], F32_TOL)
+    close(pk.autocorrelation(pg["win_33"]), pg["autocorr_33"])                      # odd size, float64: 1e-9
+    close(pk._autocorr_mean(pg["noisy_192"], 96, pg["origins_96"], True), pg["autocorr_mean_96"], F32_TOL)
+    with pytest.raises(ValueError, match="Standard deviation is zero"):
+        pk.autocorrelation(np.full((16, 16), 3.0))
+    with pytest.raises(ValueError, match="window outside"):
+        pk._autocorr_mean(pg["noisy_192"], 96, [(100, 0)], True)
+
+
+def test_many_windows_are_batched(pg, po, pk):
+    """More windows than one FFT batch holds (N = 2 x 512 -> 64 per GiB): the tail batch and the running mean."""
+    rng = np.random.default_rng(2)
+    img = rng.random((700, 640)).astype(np.float32)
+    origins = np.column_stack([rng.integers(0, 700 - 512, 70), rng.integers(0, 640 - 512, 70)])
+    close(pk._autocorr_mean(img, 512, origins, True), po.autocorr_mean(img.astype(np.float64), 512, origins))
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (96, 96), (33, 33), (40, 52)])
+def test_polar_profile_matches_restated_warp_polar(po, pk, shape):
+    rng = np.random.default_rng(3)
+    for data in (rng.random(shape) + 0.5, rng.standard_normal(shape)):            # fill value 0 outside / inside the range
+        for method in ("max", "mean", "sum"):
+            got = pk.radial_profile(data, method=method)
+            ref = po.radial_profile(data, method=method)
+            assert got.shape == ref.shape == (int(np.ceil(np.hypot(shape[0] / 2, shape[1] / 2))),)
+            np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+        got = pk.radial_profile(data, center=(shape[0] // 3, shape[1] // 2 + 1), method="mean")
+        np.testing.assert_allclose(got, po.radial_profile(data, center=(shape[0] // 3, shape[1] // 2 + 1), method="mean"),
+                                   rtol=1e-12, atol=1e-12)
+
+
+def test_power_spectra_and_cumulative_energy(pg, po, pk):
+    patch = pg["noisy_192"][5:5 + 48, 9:9 + 48]
+    cum, prof = pk._get_cumulative_energy(patch, return_profile=True)
+    ref_cum, ref_prof, ref_power = po.cumulative_energy(patch)
+    close(pk._power_spectra(patch, 48, [(0, 0)], 'hann')[0], ref_power)
+    close(prof, ref_prof)
+    np.testing.assert_allclose(cum, ref_cum, rtol=0, atol=1e-9)
+    assert cum[-1] == pytest.approx(1.0) and np.all(np.diff(cum) >= -1e-15)
+    raw = pk._power_spectra(patch, 48, [(0, 0)], None)[0]                          # no window
+    close(raw, np.abs(np.fft.fftshift(np.fft.fft2(patch.astype(np.float64)))) ** 2)
+    assert np.all(pk._get_cumulative_energy(np.zeros((16, 16))) == 0)              # zero energy edge case
+
+
+def test_denoise_fft_golden(pg, pk):
+    close(pk.denoise_fft(pg["denoise_in"], float(pg["denoise_p"])), pg["denoise_out"])
+    close(pk.denoise_fft(pg["denoise_in_f32"], float(pg["denoise_p_f32"])), pg["denoise_out_f32"], F32_TOL)
+    img = pg["denoise_in"]
+    np.testing.assert_allclose(pk.denoise_fft(img, 1.0), img, rtol=0, atol=1e-12)   # everything kept
+    # exactly ceil(p n) coefficients survive even when the cut-off falls inside a tie (Hermitian pairs)
+    out = pk.denoise_fft(img, 0.013)
+    kept = np.count_nonzero(np.abs(np.fft.fft2(out)) > 1e-9 * np.abs(np.fft.fft2(img)).max())
+    k = int(np.ceil(0.013 * img.size))
+    assert k - 1 <= kept <= k          # dropping one half of a conjugate pair leaves the real part of its partner
+
+
+@pytest.mark.parametrize("seed,window", [(0, None), (7, 64), (11, 80)])
+def test_estimate_patch_size_end_to_end(pg, po, pk, seed, window):
+    img = pg["noisy_192"]
+    np.random.seed(seed)
+    got = pk.estimate_patch_size(img, window_size=window)
+    np.random.seed(seed)
+    ref = po.estimate_patch_size(img.astype(np.float64), window_size=window)
+    assert got == ref and got is not None
+    assert 18 <= got <= 23             # honeycomb lattice with bond length 12 px: lattice constant 12 sqrt(3) = 20.8
+
+
+def test_estimate_n_max_end_to_end(pg, po, pk):
+    for img, seed in ((pg["noisy_192"], 1), (pg["lattice_192"], 2)):               # noisy image / clean image branch
+        np.random.seed(seed)
+        if pk.estimate_sigma(img) > 0.01:
+            got = pk.estimate_n_max(img, 32, n_samples=20)
+            np.random.seed(seed)
+            ref = po.estimate_n_max(img, 32, n_samples=20)
+            assert got == ref
+        else:
+            got = pk.estimate_n_max(img, 32, n_samples=20)                         # adds unseeded noise: range check only
+        assert 12 <= got <= 16
+    got = pk.estimate_n_max_from_patch(pg["noisy_192"][:64, :64].astype(np.float64), p=0.05)
+    assert 12 <= got <= 32
