@@ -11,6 +11,12 @@
  *   zk_transform_patches      <- ZPs._transform_dot_product                       (_zps.py:146-157)
  *   zk_transform_frame        <- ZPs._transform_fft_convolve                      (_zps.py:159-193)
  *   zk_*_dev                  <- same, operands already resident in HBM (bench / multi-GPU)
+ *   zk_transform_points       <- KeyPoints.extract_patches + ZPs.transform        (_keypoint.py:60-78)
+ *   zk_frame_maps             <- zmoments.to_complex / rot_maps / mirror_map      (_zmoments.py:300-316, 420-493)
+ *   zk_autocorr_mean, zk_polar_profile        <- estimate_patch_size, radial_profile  (_patch_size.py:48-100, 221-302)
+ *   zk_power_spectra, zk_denoise_fft          <- _get_cumulative_energy, denoise_fft   (_estimate_n_max.py:8-86,
+ *                                                                                      denoise/_denoise_fft.py:4-47)
+ *   zk_comm_*, zk_allgather_rows              (no counterpart: the multi-GPU exchange of north_star)
  *
  * Conventions
  *   - plain C types only; every function returns 0 on success or a negative code
