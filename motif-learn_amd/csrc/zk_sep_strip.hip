@@ -23,7 +23,10 @@ namespace {
 
 #ifndef ZK_STRIP_GROUP
 #define ZK_STRIP_GROUP 3  // column pairs per group of the sweep (2 and 3 measure alike, 4 is 4-6 % slower; one at a
-                          // time -- a scalar-memory wait per column pair -- was 12 % slower)
+                          // time -- a scalar-memory wait per column pair -- was 12 % slower).
+                          // Round 2: the explicit wait / prefetch-next / compute pipeline of zk_sep_row_pair does NOT pay
+                          // here: two table-row sets + the y row need more SGPRs than there are (79 spilled to VGPR
+                          // lanes at one column per step, 141 at two): (32, 8) 0.95 -> 1.38 ms per 2048^2.
 #endif
 
 template <int NMAX, typename T>
