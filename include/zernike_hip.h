@@ -162,6 +162,9 @@ int zk_transform_points_dev(zk_plan* plan, const void* image_dev, int dtype, int
  *   theta      : host, n_theta angles in radians (reference default linspace(0, 2 pi, 360, endpoint=False))
  * Needs the row-separable tables (zk_plan_has_path(plan, 1, dtype, ZK_PATH_SEPARABLE)); otherwise fails
  * and the caller composes zk_transform_frame with the host-side container methods.
+ * The *_dev variant returns without synchronising, except on the FIRST call with a new (folds, m_unselect, theta)
+ * option set: that call uploads a small table with a blocking copy (the plan keeps the tables of the 8 most
+ * recently used option sets, so a launch in flight never sees its table overwritten).
  */
 int zk_frame_maps(zk_plan* plan, const void* image_host, int dtype, int64_t height, int64_t width,
                   const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,

@@ -425,10 +425,14 @@ __device__ __forceinline__ void zk_batch_store_rows(const double (&z)[NP], const
                                                     double* slab, double* obase, int lane, int nv, int n_poly,
                                                     int ppp) {
   typedef double f64x2 __attribute__((ext_vector_type(2)));
+  // The output rows of a wave start 16-B aligned unless the caller's matrix starts on an odd row of an odd n_poly
+  // (a rank's block inside the gathered matrix: row 4 068 289 x 45 moments).  Then the staged image is shifted by one
+  // double, so that LDS pairs and global pairs stay 16-B aligned together and only the two ends are scalar stores.
+  const int mis = (int)(((uintptr_t)obase >> 3) & 1);  // wave-uniform (ppp * n_poly is even: every pass alike)
 #pragma unroll 1
   for (int h = 0; h * ppp < 64; ++h) {
     if (lane / ppp == h) {
-      double* const row = slab + (lane % ppp) * n_poly;
+      double* const row = slab + mis + (lane % ppp) * n_poly;
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int col = cmap[i];
@@ -440,19 +444,21 @@ __device__ __forceinline__ void zk_batch_store_rows(const double (&z)[NP], const
     live = live < 0 ? 0 : (live > ppp ? ppp : live);
     const int vd = live * n_poly;  // doubles to write in this pass
     double* const dst = obase + (long long)h * ppp * n_poly;
-    for (int k = lane; 2 * k < vd; k += 64) {
+    for (int k = lane; 2 * k < vd + mis; k += 64) {
       const f64x2 v = *(const f64x2*)(slab + 2 * k);
+      const int e = 2 * k - mis;  // output element of v.x
 #if ZK_ABLATE == 3
       asm volatile("" ::"v"(v));
 #else
-      if (2 * k + 2 <= vd) {
+      if (e >= 0 && e + 2 <= vd) {
 #if ZK_STORE_NT
-        __builtin_nontemporal_store(v, (f64x2*)(dst + 2 * k));
+        __builtin_nontemporal_store(v, (f64x2*)(dst + e));
 #else
-        *(f64x2*)(dst + 2 * k) = v;
+        *(f64x2*)(dst + e) = v;
 #endif
       } else {
-        dst[2 * k] = v.x;
+        if (e >= 0 && e < vd) dst[e] = v.x;
+        if (e + 1 >= 0 && e + 1 < vd) dst[e + 1] = v.y;
       }
 #endif
     }

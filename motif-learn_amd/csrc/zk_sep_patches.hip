@@ -431,7 +431,7 @@ bool zk_sep_patches_available(const zk_plan* p, int dtype) {
 int ZK_GROUP_FN(zk_launch_sep_patches)(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out,
                                        hipStream_t s) {
 #if ZK_NMAX_GROUP == 0
-  if (((uintptr_t)in & (dtype == ZK_F32 ? 3 : 7)) || ((uintptr_t)out & 15))  // element-aligned DMA, 16-B stores
+  if (((uintptr_t)in & (dtype == ZK_F32 ? 3 : 7)) || ((uintptr_t)out & 7))  // element-aligned operands
     return zk_launch_generic_patches(p, in, dtype, n_patches, out, s);
   if (p->sep->kernel_nmax > 16) return zk_launch_sep_patches_g2(p, in, dtype, n_patches, out, s);
   if (p->sep->kernel_nmax > 12) return zk_launch_sep_patches_g1(p, in, dtype, n_patches, out, s);

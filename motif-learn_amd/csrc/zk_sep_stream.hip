@@ -283,7 +283,7 @@ int ZK_GROUP_FN(zk_launch_sep_stream)(zk_plan* p, const void* in, int dtype, int
 #if ZK_NMAX_GROUP == 0
   if (p->sep->kernel_nmax > 12) return zk_launch_sep_stream_g1(p, in, dtype, n_patches, out, s);
 #endif
-  if (((uintptr_t)in & (dtype == ZK_F32 ? 3 : 7)) || ((uintptr_t)out & 15))  // element-aligned DMA, 16-B stores
+  if (((uintptr_t)in & (dtype == ZK_F32 ? 3 : 7)) || ((uintptr_t)out & 7))  // element-aligned operands
     return zk_launch_generic_patches(p, in, dtype, n_patches, out, s);
   if (dtype == ZK_F64) return launch_t<double>(p, in, n_patches, out, s);
   return launch_t<float>(p, in, n_patches, out, s);

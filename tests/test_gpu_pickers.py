@@ -94,7 +94,7 @@ def test_denoise_fft_golden(pg, pk):
     out = pk.denoise_fft(img, 0.013)
     kept = np.count_nonzero(np.abs(np.fft.fft2(out)) > 1e-9 * np.abs(np.fft.fft2(img)).max())
     k = int(np.ceil(0.013 * img.size))
-    assert k - 1 <= kept <= k          # dropping one half of a conjugate pair leaves the real part of its partner
+    assert k - 1 <= kept <= k + 1      # a conjugate pair cut in two shows up as both halves at half weight in the real result
 
 
 @pytest.mark.parametrize("seed,window", [(0, None), (7, 64), (11, 80)])

@@ -189,3 +189,25 @@ def test_device_entry_points_check_their_operands():
     with pytest.raises(ValueError, match="contiguous"):
         D.frame_moments_device(plan, torch.zeros((16, 32), device="cuda")[:, ::2])
     assert torch.cuda.current_device() == 0                                  # entry points leave the device alone
+
+
+@pytest.mark.parametrize("n_max,size", [(8, 32), (12, 64), (8, 24)])
+def test_batch_kernels_write_into_odd_rows_of_the_gathered_matrix(n_max, size):
+    """A rank's block inside the gathered (N_total, n_poly) matrix starts at row rank * n_local -- an odd row of an odd
+    n_poly is only 8-byte aligned.  The fast batch kernels (row-pair and stream) must take it (not fall back to the
+    generic kernel) and produce the same bits as into an aligned buffer."""
+    torch = _torch()
+    from mtflearn_amd.distributed import patch_moments_device
+    z = _zps(n_max, size)
+    plan = z._device_plan()
+    n_poly = len(z.n)
+    assert n_poly % 2 == 1
+    n = 98304 + 1237                                       # enough patches for ZK_PATH_AUTO to pick the stream kernel at K = 24
+    p = torch.rand((n, size, size), device="cuda")
+    aligned = patch_moments_device(plan, p)
+    big = torch.full((n + 3, n_poly), float("nan"), dtype=torch.float64, device="cuda")
+    for row0 in (1, 2, 3):
+        big.fill_(float("nan"))
+        patch_moments_device(plan, p, out=big[row0:row0 + n])
+        assert torch.equal(big[row0:row0 + n], aligned), row0
+        assert torch.isnan(big[:row0]).all() and torch.isnan(big[row0 + n:]).all()      # nothing written outside the block
