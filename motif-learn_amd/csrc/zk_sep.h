@@ -496,7 +496,9 @@ __device__ __forceinline__ void zk_sep_row_pair(zk_sep_acc<NMAX, MASK>& acc, con
   const ZK_CONST double* pr = px + cmin * ZK_SEP_ROW;
   int c = cmin;
   // (the n_max 11-12 instances are register-capped at 256 for two waves per SIMD and already spill: the extra live
-  //  row costs them more than the waits did -- 2048^2 frame: (32, 12) 2.03 -> 2.50 ms, (64, 12) 5.17 -> 5.79)
+  //  row costs them more than the waits did -- 2048^2 frame: (32, 12) 2.03 -> 2.50 ms, (64, 12) 5.17 -> 5.79; a
+  //  scalar-only form -- this pixel's LDS reads and the next pixel's row requested together, one wait per pixel, no
+  //  extra VGPR, 254 registers without spills -- lost too: 2.16 / 5.92 ms: the compiler's 4-pixel schedule stays)
   if constexpr (ZK_ROW_PAIR_PIPE && !(NMAX == 12 && MASK == 15)) {
   constexpr int NA = NMAX + 1;
   double an = tf[0], bn = tb[0], cn = bf[0], dn = bb[0], Pn[NA];
