@@ -43,6 +43,13 @@ extern "C" {
 /* element type of the image / patch operand */
 #define ZK_F32 0
 #define ZK_F64 1
+/* Narrow detector formats, accepted by the HOST-buffer entry points only (zk_transform_patches / _frame / _points,
+ * zk_frame_maps): the bytes cross PCIe as they are (1-2 B per pixel instead of 4) and are widened to float32 on the
+ * device, which is exact -- the moments equal those of NumPy's float64 promotion of the same integers
+ * (reference _zps.py:151-155 upcasts whatever dtype it is given). */
+#define ZK_U8  2
+#define ZK_U16 3
+#define ZK_I16 4
 
 /* argument-error codes (runtime failures are -hipError_t, i.e. -1 .. -1999) */
 #define ZK_E_BADARG   (-10001)

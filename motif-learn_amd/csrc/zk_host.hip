@@ -30,14 +30,43 @@ struct zk_host_ring {
   hipStream_t s_in = nullptr, s_out = nullptr;
   void* d_frame = nullptr;                 // whole frame (+ points) of the dense / key-point calls
   size_t frame_cap = 0;
+  void* d_raw[ZK_RING_SLOTS] = {};         // narrow inputs (ZK_U8 / U16 / I16) as they arrive, before widening
+  size_t raw_cap[ZK_RING_SLOTS] = {};
 };
 
 namespace {
 
-size_t elem_size(int dtype) { return dtype == ZK_F32 ? 4 : 8; }
+size_t elem_size(int dtype) { return dtype == ZK_U8 ? 1 : (dtype == ZK_U16 || dtype == ZK_I16) ? 2 : dtype == ZK_F32 ? 4 : 8; }
+bool is_narrow(int dtype) { return dtype == ZK_U8 || dtype == ZK_U16 || dtype == ZK_I16; }
+int kernel_dtype(int dtype) { return is_narrow(dtype) ? ZK_F32 : dtype; }  // what the kernels read
 
 int check_dtype(int dtype) {
-  if (dtype != ZK_F32 && dtype != ZK_F64) return zk_fail(ZK_E_BADARG, "dtype must be ZK_F32 or ZK_F64");
+  if (dtype < ZK_F32 || dtype > ZK_I16) return zk_fail(ZK_E_BADARG, "dtype must be ZK_F32, ZK_F64, ZK_U8, ZK_U16 or ZK_I16");
+  return 0;
+}
+
+// narrow integers -> float32 (exact), 4 elements per thread
+template <typename S>
+__global__ __launch_bounds__(256) void widen_kernel(const S* __restrict__ in, float* __restrict__ out, long long n) {
+  const long long t = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t + 3 < n) {
+    float4 v;
+    v.x = (float)in[t];
+    v.y = (float)in[t + 1];
+    v.z = (float)in[t + 2];
+    v.w = (float)in[t + 3];
+    *(float4*)(out + t) = v;
+  } else {
+    for (long long k = t; k < n; ++k) out[k] = (float)in[k];
+  }
+}
+
+int widen(int dtype, const void* in, float* out, long long n, hipStream_t s) {
+  const unsigned blocks = (unsigned)((n + 1023) / 1024);
+  if (dtype == ZK_U8) hipLaunchKernelGGL(widen_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, (const uint8_t*)in, out, n);
+  else if (dtype == ZK_U16) hipLaunchKernelGGL(widen_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)in, out, n);
+  else hipLaunchKernelGGL(widen_kernel<int16_t>, dim3(blocks), dim3(256), 0, s, (const int16_t*)in, out, n);
+  ZK_HIP(hipGetLastError());
   return 0;
 }
 
@@ -111,6 +140,7 @@ void zk_host_release(zk_plan* p) {
   if (r->s_out) (void)hipStreamSynchronize(r->s_out);
   for (int k = 0; k < ZK_RING_SLOTS; ++k) {
     if (r->d_in[k]) (void)hipFree(r->d_in[k]);
+    if (r->d_raw[k]) (void)hipFree(r->d_raw[k]);
     if (r->d_out[k]) (void)hipFree(r->d_out[k]);
     if (r->ev_in[k]) (void)hipEventDestroy(r->ev_in[k]);
     if (r->ev_k[k]) (void)hipEventDestroy(r->ev_k[k]);
@@ -171,7 +201,11 @@ extern "C" int zk_transform_patches(zk_plan* p, const void* patches_host, int dt
   ZK_ON_PLAN_DEVICE(p);
   zk_host_ring* r;
   if ((rc = ring_get(p, &r))) return rc;
-  const size_t in_unit = (size_t)p->size * p->size * elem_size(dtype), out_unit = (size_t)p->n_poly * sizeof(double);
+  const int kdt = kernel_dtype(dtype);
+  const bool narrow = is_narrow(dtype);
+  const size_t px_per = (size_t)p->size * p->size;
+  const size_t raw_unit = px_per * elem_size(dtype), in_unit = px_per * elem_size(kdt),
+               out_unit = (size_t)p->n_poly * sizeof(double);
   int64_t chunk = (int64_t)(chunk_bytes(p) / (in_unit + out_unit)) & ~(int64_t)255;  // whole waves of 64 patches
   if (chunk < 256) chunk = 256;
   if (chunk > n_patches) chunk = n_patches;
@@ -187,15 +221,18 @@ extern "C" int zk_transform_patches(zk_plan* p, const void* patches_host, int dt
       [&](int c, int slot) -> int {
         int e = slot_acquire(r, slot);
         if (!e) e = zk_ensure(&r->d_in[slot], &r->in_cap[slot], (size_t)chunk * in_unit);
+        if (!e && narrow) e = zk_ensure(&r->d_raw[slot], &r->raw_cap[slot], (size_t)chunk * raw_unit);
         if (!e) e = zk_ensure(&r->d_out[slot], &r->out_cap[slot], (size_t)chunk * out_unit);
         if (e) return e;
-        // the slot's previous kernel must have consumed d_in before the next H2D overwrites it
+        // the slot's previous kernels must have consumed the landing buffer before the next H2D overwrites it
         if (c >= ZK_RING_SLOTS) ZK_HIP(hipStreamWaitEvent(r->s_in, r->ev_k[slot], 0));
-        ZK_HIP(hipMemcpyAsync(r->d_in[slot], (const char*)patches_host + (size_t)c * chunk * in_unit,
-                              (size_t)count(c) * in_unit, hipMemcpyHostToDevice, r->s_in));
+        ZK_HIP(hipMemcpyAsync(narrow ? r->d_raw[slot] : r->d_in[slot], (const char*)patches_host + (size_t)c * chunk * raw_unit,
+                              (size_t)count(c) * raw_unit, hipMemcpyHostToDevice, r->s_in));
         ZK_HIP(hipEventRecord(r->ev_in[slot], r->s_in));
         ZK_HIP(hipStreamWaitEvent(p->stream, r->ev_in[slot], 0));
-        if ((e = zk_transform_patches_dev(p, r->d_in[slot], dtype, count(c), (double*)r->d_out[slot], p->stream))) return e;
+        if (narrow && (e = widen(dtype, r->d_raw[slot], (float*)r->d_in[slot], (long long)count(c) * (long long)px_per, p->stream)))
+          return e;
+        if ((e = zk_transform_patches_dev(p, r->d_in[slot], kdt, count(c), (double*)r->d_out[slot], p->stream))) return e;
         ZK_HIP(hipEventRecord(r->ev_k[slot], p->stream));
         return 0;
       },
@@ -226,11 +263,19 @@ int band_to_host(double* host, const double* d_src, int64_t planes, int64_t H, i
   return 0;
 }
 
-int frame_up(zk_plan* p, zk_host_ring* r, const void* image_host, size_t bytes, size_t extra) {
+// the whole frame onto the device as the kernels' element type (narrow formats: raw bytes up, widened there);
+// `bytes` = size in the kernels' type, `extra` = room behind it for the caller
+int frame_up(zk_plan* p, zk_host_ring* r, const void* image_host, int dtype, long long n_px, size_t bytes, size_t extra) {
   int rc = zk_ensure(&r->d_frame, &r->frame_cap, bytes + extra);
   if (rc) return rc;
-  ZK_HIP(hipMemcpyAsync(r->d_frame, image_host, bytes, hipMemcpyHostToDevice, p->stream));
-  return 0;
+  if (!is_narrow(dtype)) {
+    ZK_HIP(hipMemcpyAsync(r->d_frame, image_host, bytes, hipMemcpyHostToDevice, p->stream));
+    return 0;
+  }
+  const size_t raw = (size_t)n_px * elem_size(dtype);
+  if ((rc = zk_ensure(&r->d_raw[0], &r->raw_cap[0], raw))) return rc;
+  ZK_HIP(hipMemcpyAsync(r->d_raw[0], image_host, raw, hipMemcpyHostToDevice, p->stream));
+  return widen(dtype, r->d_raw[0], (float*)r->d_frame, n_px, p->stream);
 }
 
 int64_t band_rows(const zk_plan* p, size_t row_bytes, int64_t H) {
@@ -251,7 +296,8 @@ extern "C" int zk_transform_frame(zk_plan* p, const void* image_host, int dtype,
   ZK_ON_PLAN_DEVICE(p);
   zk_host_ring* r;
   if ((rc = ring_get(p, &r))) return rc;
-  if ((rc = frame_up(p, r, image_host, (size_t)H * W * elem_size(dtype), 0))) return ring_drain(p, r, rc);
+  const int kdt = kernel_dtype(dtype);
+  if ((rc = frame_up(p, r, image_host, dtype, (long long)H * W, (size_t)H * W * elem_size(kdt), 0))) return ring_drain(p, r, rc);
   const size_t row_bytes = (size_t)p->n_poly * W * sizeof(double);
   const int64_t band = band_rows(p, row_bytes, H);
   const int n_chunks = (int)((H + band - 1) / band);
@@ -261,7 +307,7 @@ extern "C" int zk_transform_frame(zk_plan* p, const void* image_host, int dtype,
       [&](int c, int slot) -> int {
         int e = slot_acquire(r, slot);
         if (!e) e = zk_ensure(&r->d_out[slot], &r->out_cap[slot], (size_t)band * row_bytes);
-        if (!e) e = zk_transform_frame_dev(p, r->d_frame, dtype, H, W, c * band, rows(c), (double*)r->d_out[slot], p->stream);
+        if (!e) e = zk_transform_frame_dev(p, r->d_frame, kdt, H, W, c * band, rows(c), (double*)r->d_out[slot], p->stream);
         if (e) return e;
         ZK_HIP(hipEventRecord(r->ev_k[slot], p->stream));
         return 0;
@@ -291,7 +337,8 @@ extern "C" int zk_frame_maps(zk_plan* p, const void* image_host, int dtype, int6
   ZK_ON_PLAN_DEVICE(p);
   zk_host_ring* r;
   if ((rc = ring_get(p, &r))) return rc;
-  if ((rc = frame_up(p, r, image_host, (size_t)H * W * elem_size(dtype), 0))) return ring_drain(p, r, rc);
+  const int kdt = kernel_dtype(dtype);
+  if ((rc = frame_up(p, r, image_host, dtype, (long long)H * W, (size_t)H * W * elem_size(kdt), 0))) return ring_drain(p, r, rc);
   const int64_t nc = zk_complex_count(zk_full_set_nmax(p));
   const int64_t pl_rot = rot_host ? n_folds : 0, pl_abs = abs_host ? nc : 0, pl_mir = mirror_host ? 1 : 0;
   const size_t row_bytes = (size_t)(pl_rot + pl_abs + pl_mir + 1) * W * sizeof(double);
@@ -309,7 +356,7 @@ extern "C" int zk_frame_maps(zk_plan* p, const void* image_host, int dtype, int6
         int e = slot_acquire(r, slot);
         if (!e) e = zk_ensure(&r->d_out[slot], &r->out_cap[slot], (size_t)band * row_bytes);
         if (!e)
-          e = zk_frame_maps_dev(p, r->d_frame, dtype, H, W, c * band, rows(c), folds, n_folds, m_unselect, n_unselect, p_norm,
+          e = zk_frame_maps_dev(p, r->d_frame, kdt, H, W, c * band, rows(c), folds, n_folds, m_unselect, n_unselect, p_norm,
                                 theta, n_theta, d_rot(c, slot), d_abs(c, slot), d_mir(c, slot), p->stream);
         if (e) return e;
         ZK_HIP(hipEventRecord(r->ev_k[slot], p->stream));
@@ -343,10 +390,11 @@ extern "C" int zk_transform_points(zk_plan* p, const void* image_host, int dtype
   ZK_ON_PLAN_DEVICE(p);
   zk_host_ring* r;
   if ((rc = ring_get(p, &r))) return rc;
-  const size_t img_bytes = (size_t)H * W * elem_size(dtype);
+  const int kdt = kernel_dtype(dtype);
+  const size_t img_bytes = (size_t)H * W * elem_size(kdt);
   const size_t img_pad = (img_bytes + 255) & ~(size_t)255;
   const size_t pts_bytes = (size_t)n_points * 2 * sizeof(int32_t);
-  if ((rc = frame_up(p, r, image_host, img_bytes, img_pad - img_bytes + pts_bytes))) return ring_drain(p, r, rc);
+  if ((rc = frame_up(p, r, image_host, dtype, (long long)H * W, img_bytes, img_pad - img_bytes + pts_bytes))) return ring_drain(p, r, rc);
   int32_t* d_pts = (int32_t*)((char*)r->d_frame + img_pad);
   {
     const hipError_t e = hipMemcpyAsync(d_pts, points_host, pts_bytes, hipMemcpyHostToDevice, p->stream);
@@ -364,7 +412,7 @@ extern "C" int zk_transform_points(zk_plan* p, const void* image_host, int dtype
         int e = slot_acquire(r, slot);
         if (!e) e = zk_ensure(&r->d_out[slot], &r->out_cap[slot], (size_t)chunk * out_unit);
         if (!e)
-          e = zk_transform_points_dev(p, r->d_frame, dtype, H, W, d_pts + 2 * c * chunk, count(c), (double*)r->d_out[slot],
+          e = zk_transform_points_dev(p, r->d_frame, kdt, H, W, d_pts + 2 * c * chunk, count(c), (double*)r->d_out[slot],
                                       p->stream);
         if (e) return e;
         ZK_HIP(hipEventRecord(r->ev_k[slot], p->stream));

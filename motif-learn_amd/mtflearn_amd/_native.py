@@ -15,6 +15,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, 
 import numpy as np
 
 ZK_F32, ZK_F64 = 0, 1
+ZK_U8, ZK_U16, ZK_I16 = 2, 3, 4   # host-buffer entry points only: widened to float32 on the device (exact)
 PATH_AUTO, PATH_GENERIC, PATH_FOLDED, PATH_SEPARABLE, PATH_STREAM = 0, 1, 2, 3, 4
 OP_POINTS, OP_MAPS = 1, 2
 PATH_NAMES = {PATH_GENERIC: "generic", PATH_FOLDED: "folded", PATH_SEPARABLE: "separable", PATH_STREAM: "stream"}
@@ -145,12 +146,13 @@ def device_count():
 
 
 def dtype_code(dtype):
-    """ZK_F32 / ZK_F64 for the two element types the kernels read natively, else None."""
+    """ZK_F32 / ZK_F64 for the two element types the kernels read natively, ZK_U8 / ZK_U16 / ZK_I16 for the narrow
+    detector formats the host-buffer entry points widen on the device, else None."""
     if dtype == np.float32:
         return ZK_F32
     if dtype == np.float64:
         return ZK_F64
-    return None
+    return {np.dtype(np.uint8): ZK_U8, np.dtype(np.uint16): ZK_U16, np.dtype(np.int16): ZK_I16}.get(np.dtype(dtype))
 
 
 class PinnedPool:

@@ -169,16 +169,25 @@ class ZPs(BaseEstimator, TransformerMixin):
 
     @staticmethod
     def _device_operand(images):
-        """C-contiguous float32 / float64 view or copy of a real-valued array."""
+        """C-contiguous array in one of the element types the host entry points take.
+
+        float32 / float64 pass as they are.  The usual detector formats -- uint8, uint16, int16 (and bool / int8,
+        re-labelled or widened to those) -- are exact in float32, which is what NumPy's promotion to float64 would
+        compute on: they cross PCIe as they are (1-2 bytes per pixel instead of 4, and no host-side ``astype`` pass)
+        and are widened on the device.  float16 goes to float32, wider integers to float64."""
         if np.iscomplexobj(images):
             raise TypeError("complex images are not supported by the HIP kernels")
-        if images.dtype not in (np.float32, np.float64):
-            # what NumPy's promotion to float64 would compute: bool, float16 and integers of up to 16 bits
-            # (the usual detector formats) are exact in float32 as well -- half the bytes to move and the
-            # float32 kernels; wider integers go to float64
-            narrow = images.dtype == np.bool_ or images.dtype == np.float16 or \
-                (images.dtype.kind in "iu" and images.dtype.itemsize <= 2)
-            images = images.astype(np.float32 if narrow else np.float64)
+        dt = images.dtype
+        if dt in (np.float32, np.float64, np.uint8, np.uint16, np.int16):
+            pass
+        elif dt == np.bool_:
+            images = images.view(np.uint8) if images.flags.c_contiguous else images.astype(np.uint8)
+        elif dt == np.int8:
+            images = images.astype(np.int16)
+        elif dt == np.float16:
+            images = images.astype(np.float32)
+        else:
+            images = images.astype(np.float64)
         return np.ascontiguousarray(images)
 
     # ------------------------------------------------------------------ transform
@@ -275,6 +284,8 @@ class ZPs(BaseEstimator, TransformerMixin):
         operand = self._device_operand(image)
         plan = self._device_plan()
         code = _native.dtype_code(operand.dtype)
+        if code not in (_native.ZK_F32, _native.ZK_F64):
+            code = _native.ZK_F32          # detector formats are widened to float32 on the device
         fused = (plan.supports(_native.OP_MAPS, code) and p in (2, None) and len(folds) <= 8
                  and all(int(f) == f and f > 0 for f in folds))
         out = {}

@@ -211,3 +211,29 @@ def test_batch_kernels_write_into_odd_rows_of_the_gathered_matrix(n_max, size):
         patch_moments_device(plan, p, out=big[row0:row0 + n])
         assert torch.equal(big[row0:row0 + n], aligned), row0
         assert torch.isnan(big[:row0]).all() and torch.isnan(big[row0 + n:]).all()      # nothing written outside the block
+
+
+@pytest.mark.parametrize("dt", [np.uint8, np.uint16, np.int16, np.bool_, np.int8])
+def test_detector_formats_are_widened_on_the_device(dt):
+    """uint8 / uint16 / int16 inputs cross PCIe as they are and are widened to float32 on the device: the moments equal
+    those of the float64 promotion NumPy (the reference) would compute on, for every host entry point, chunked or not."""
+    from oracle import zernike_oracle as zo
+    rng = np.random.default_rng(5)
+    hi = {np.uint8: 255, np.uint16: 65535, np.int16: 32767, np.bool_: 2, np.int8: 127}[dt]
+    lo = {np.int16: -32768, np.int8: -128}.get(dt, 0)
+    z = _zps(8, 32)
+    plan = z._device_plan()
+    patches = rng.integers(lo, hi, (3000, 32, 32)).astype(dt)
+    frame = rng.integers(lo, hi, (90, 131)).astype(dt)
+    pts = np.column_stack([rng.integers(0, 131, 500), rng.integers(0, 90, 500)])
+    ref_p = zo.moments_patches(patches.astype(np.float64), z.polynomials)
+    ref_f = zo.moments_frame_direct(frame.astype(np.float64), z.polynomials)
+    for chunk in (0, 1 << 20):
+        plan.set_host_chunk(chunk)
+        rel_close(z.transform(patches).data, ref_p)
+        rel_close(z.transform(frame).data, ref_f)
+        np.testing.assert_array_equal(z.transform_at(frame, pts).data, z.transform_at(frame.astype(np.float32), pts).data)
+        a, b = z.symmetry_maps(frame), z.symmetry_maps(frame.astype(np.float32))
+        for key in ("rot_maps", "abs", "mirror_map"):
+            np.testing.assert_array_equal(a[key], b[key])
+    plan.set_host_chunk(0)

@@ -227,15 +227,17 @@ def _declared_symbols():
 
 
 def test_device_operand_dtypes():
-    """Narrow detector formats go to float32 (exact), wide integers to float64, as NumPy's promotion would give."""
-    from mtflearn_amd import ZPs
-    for dt, want in [(np.uint8, np.float32), (np.int16, np.float32), (np.uint16, np.float32), (np.bool_, np.float32),
-                     (np.float16, np.float32), (np.int32, np.float64), (np.uint32, np.float64), (np.int64, np.float64),
-                     (np.float32, np.float32), (np.float64, np.float64)]:
-        a = (np.arange(24).reshape(4, 6) % 2 if dt == np.bool_ else np.arange(24).reshape(4, 6) * 997 % 251).astype(dt)
-        op = ZPs._device_operand(a[:, ::2])
-        assert op.dtype == want and op.flags.c_contiguous
-        np.testing.assert_array_equal(op.astype(np.float64), a[:, ::2].astype(np.float64))
+    """Detector formats (uint8 / uint16 / int16, bool and int8 re-labelled) travel as they are and are widened on the
+    device (exact in float32); float16 goes to float32, wide integers to float64, as NumPy's promotion would give."""
+    from mtflearn_amd import ZPs, _native
+    for dt, want in [(np.uint8, np.uint8), (np.int16, np.int16), (np.uint16, np.uint16), (np.bool_, np.uint8),
+                     (np.int8, np.int16), (np.float16, np.float32), (np.int32, np.float64), (np.uint32, np.float64),
+                     (np.int64, np.float64), (np.float32, np.float32), (np.float64, np.float64)]:
+        a = (np.arange(24).reshape(4, 6) % 2 if dt == np.bool_ else np.arange(24).reshape(4, 6) * 997 % 251 - (100 if dt == np.int8 else 0)).astype(dt)
+        for view in (a, a[:, ::2]):
+            op = ZPs._device_operand(view)
+            assert op.dtype == want and op.flags.c_contiguous and _native.dtype_code(op.dtype) is not None
+            np.testing.assert_array_equal(op.astype(np.float64), view.astype(np.float64))
     with pytest.raises(TypeError):
         ZPs._device_operand(np.zeros((2, 2), np.complex64))
 
