@@ -291,6 +291,24 @@ int zk_power_spectra(int device, const void* image_host, int dtype, int64_t heig
 int zk_denoise_fft(int device, const void* image_host, int dtype, int64_t height, int64_t width, double p,
                    double* out_host);
 
+/* ------------------------------------------------------------------------------------------------------
+ * First downstream consumer of the moment matrix: the two streaming passes of
+ *   pca(X, n_components)   reference features/_dimension_reduction.py:3-6 (sklearn PCA(n).fit_transform(X))
+ * on a float64 matrix X (N, D), D <= 127 (45 moments at n_max 8).
+ *   zk_gram[_dev]     G (D+1, D+1) = [X | 1]^T [X | 1]: X^T X with the column sums in the last row / column and N in
+ *                     the corner -- everything the covariance needs, one pass over X.
+ *   zk_project[_dev]  Y (N, k) = (X - mean) components^T, k <= 16.
+ * The D x D eigen-problem between them is solved on the host (LAPACK, as scikit-learn's "covariance_eigh" solver does).
+ * The host-buffer zk_gram leaves X on the device and hands the copy back (X_dev_out) for zk_project, which frees it
+ * when free_x is non-zero.
+ * ------------------------------------------------------------------------------------------------------ */
+int zk_gram(int device, const double* X_host, int64_t n_rows, int n_features, double* gram_host, void** X_dev_out);
+int zk_project(int device, const void* X_dev, int64_t n_rows, int n_features, const double* mean_host,
+               const double* components_host, int n_components, double* Y_host, int free_x);
+int zk_gram_dev(int device, const double* X_dev, int64_t n_rows, int n_features, double* gram_dev, void* hip_stream);
+int zk_project_dev(int device, const double* X_dev, int64_t n_rows, int n_features, const double* mean_dev,
+                   const double* components_dev, int n_components, double* Y_dev, void* hip_stream);
+
 /* Device memory for callers that have no allocator of their own (a NumPy / C user of the *_dev entry points). */
 int zk_device_malloc(int device, int64_t bytes, void** out_dev);
 int zk_device_free(int device, void* dev);

@@ -5,7 +5,8 @@ from .moments import (zmoments, construct_rot_maps_matrix, construct_complex_mat
                       construct_real_matrix, nm2j, nm2j_complex, check_array1d)
 from .pickers import (estimate_patch_size, radial_profile, estimate_n_max, estimate_n_max_from_patch,
                       _get_cumulative_energy)
+from .consumers import pca
 
 __all__ = ["ZPs", "zmoments", "construct_rot_maps_matrix", "construct_complex_matrix",
            "construct_real_matrix", "nm2j", "nm2j_complex", "check_array1d",
-           "estimate_patch_size", "radial_profile", "estimate_n_max", "estimate_n_max_from_patch"]
+           "estimate_patch_size", "radial_profile", "estimate_n_max", "estimate_n_max_from_patch", "pca"]

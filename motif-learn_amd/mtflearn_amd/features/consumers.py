@@ -1,0 +1,78 @@
+"""Downstream consumers of the moment matrix.
+
+``pca(X, n_components)`` replaces ``mtflearn.features.pca`` (reference ``mtflearn/features/_dimension_reduction.py:3-6``:
+``sklearn.decomposition.PCA(n_components).fit_transform(X)``) with the two passes over ``X`` on the GPU -- the Gram
+matrix with the column sums (``zk_gram``) and the projection (``zk_project``), ``csrc/zk_consumers.hip`` -- and the
+``D x D`` eigen-problem between them on the host, following the arithmetic of scikit-learn's ``covariance_eigh`` solver
+(``sklearn/decomposition/_pca.py``: ``C = (X^T X - n mean mean^T) / (n - 1)``, ``eigh``, descending order, negative
+eigenvalues clipped, ``svd_flip(u_based_decision=False)``: the entry of largest magnitude of every component is positive).
+scikit-learn is a dependency of the reference and of this package, so parity is tested against it directly
+(``tests/test_gpu_consumers.py``).  scikit-learn picks that solver itself when ``n_samples >= 10 n_features`` (the
+usual case: millions of patches x 45 moments); for smaller inputs it uses an SVD of the centred matrix, which this
+routine does not imitate -- same subspace and signs, last digits may differ.
+
+The reference's clustering wrappers (``kmeans_lbs`` / ``gmm_lbs``: scikit-learn estimators with their own random
+initialisation) and ``ForceGraph8`` (a numba layout optimiser) are not rebuilt.
+"""
+from __future__ import annotations
+
+from ctypes import POINTER, byref, c_double, c_void_p
+
+import numpy as np
+
+from .. import _native
+from .pickers import _device
+
+__all__ = ["pca"]
+
+
+def _covariance_eigh(gram, n_rows):
+    """(mean, components (D, D) rows sorted by decreasing variance, explained_variance) from G = [X|1]^T [X|1]."""
+    d = gram.shape[0] - 1
+    mean = gram[d, :d] / n_rows
+    cov = gram[:d, :d] - n_rows * np.outer(mean, mean)
+    cov /= n_rows - 1
+    eigenvals, eigenvecs = np.linalg.eigh(cov)
+    eigenvals = np.flip(eigenvals, axis=0).copy()
+    eigenvecs = np.flip(eigenvecs, axis=1)
+    eigenvals[eigenvals < 0.0] = 0.0
+    vt = eigenvecs.T.copy()
+    idx = np.argmax(np.abs(vt), axis=1)                                     # svd_flip(u_based_decision=False)
+    signs = np.sign(vt[np.arange(vt.shape[0]), idx])
+    vt *= signs[:, None]
+    return mean, vt, eigenvals
+
+
+def pca(X, n_components=2, reconstruct=False):
+    """First ``n_components`` principal-component scores of ``X`` (N, D) -> (N, n_components) float64."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError(f"Expected 2D array, got {X.ndim}D array instead")
+    n, d = X.shape
+    k = min(n, d) if n_components is None else n_components
+    if not isinstance(k, (int, np.integer)) or not 1 <= k <= min(n, d):
+        raise ValueError(f"n_components={n_components!r} must be between 1 and min(n_samples, n_features)={min(n, d)}")
+    if n < 2:
+        raise ValueError("PCA needs at least two samples")
+    lib = _native.load()
+    if _native.device_count() == 0:
+        raise RuntimeError("no HIP device visible: mtflearn_amd computes on MI355X only (there is no CPU fallback)")
+    dev = _device()
+    gram = np.empty((d + 1, d + 1), dtype=np.float64)
+    x_dev = c_void_p()
+    _native.check(lib.zk_gram(dev, X.ctypes.data_as(POINTER(c_double)), n, d, gram.ctypes.data_as(POINTER(c_double)),
+                              byref(x_dev)), "zk_gram")
+    mean, vt, _ = _covariance_eigh(gram, n)
+    out = _native.pinned.empty((n, k))
+    done = 0
+    while done < k:                                                          # at most 16 components per launch
+        kk = min(16, k - done)
+        comp = np.ascontiguousarray(vt[done:done + kk])
+        part = out if kk == k else np.empty((n, kk), dtype=np.float64)
+        _native.check(lib.zk_project(dev, x_dev, n, d, mean.ctypes.data_as(POINTER(c_double)),
+                                     comp.ctypes.data_as(POINTER(c_double)), kk, part.ctypes.data_as(POINTER(c_double)),
+                                     int(done + kk == k)), "zk_project")
+        if part is not out:
+            out[:, done:done + kk] = part
+        done += kk
+    return out
