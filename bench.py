@@ -158,9 +158,9 @@ def _kernel_source_hash():
     import glob
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "motif-learn_amd", "csrc", "*"))):
-        if path.endswith((".hip", ".h")):
-            h.update(open(path, "rb").read())
+    # the sources that define the timed batch kernel and its tables
+    for name in ("zk_sep_patches.hip", "zk_sep.h", "zk_sep.hip", "zk_fold.h", "zk_internal.h"):
+        h.update(open(os.path.join(ROOT, "motif-learn_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
 
