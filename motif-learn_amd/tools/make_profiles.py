@@ -48,7 +48,7 @@ with open(os.path.join(P, f"{TAG}_pmc_hbm.txt"), "w") as f:
 #   read  = 2 x FETCH_SIZE x 1024 = {rec['read_bytes']:.4e} B  (= {rec['read_bytes'] / n:.1f} B/patch: 30 of 32 patch rows x 128 B; rows 0 and 31 lie outside the disk and are never fetched)
 #   write = WRITE_SIZE x 1024     = {rec['write_bytes']:.4e} B  (= {rec['write_bytes'] / n:.1f} B/patch: 45 moments x 8 B)
 #   traffic = {rec['hbm_bytes_per_launch']:.4e} B per launch vs algorithmic 4456 B x N = {4456 * n:.4e} B  -> no wasted re-reads ({rec['hbm_bytes_per_launch'] / (4456 * n):.2f} x algorithmic)
-# recorded for bench.py in profiles/traffic.json together with the sha256 of motif-learn_amd/csrc/*.{{hip,h}} it was taken on
+# recorded for bench.py in profiles/traffic.json together with the sha256 of the batch kernel sources (zk_sep_patches.hip, zk_sep.h, zk_sep.hip, zk_fold.h, zk_internal.h) it was taken on
 # (kernel_source_sha {rec['kernel_source_sha']}, git {rec['git']}).
 """)
 
