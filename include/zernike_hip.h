@@ -290,6 +290,10 @@ int zk_power_spectra(int device, const void* image_host, int dtype, int64_t heig
                      const int32_t* origins_yx, int n_windows, const double* window_1d, double* out_host);
 int zk_denoise_fft(int device, const void* image_host, int dtype, int64_t height, int64_t width, double p,
                    double* out_host);
+/* skimage.restoration.estimate_sigma of a 2-D image, as estimate_n_max uses it (_estimate_n_max.py:109): median of the
+ * non-zero |db2 diagonal detail coefficients| (PyWavelets dwtn, mode 'symmetric') / 0.6745 -- restated from scikit-image /
+ * PyWavelets, which are not installed here (parity unpinned).  Coefficients and the median's order statistics on the device. */
+int zk_wavelet_sigma(int device, const void* image_host, int dtype, int64_t height, int64_t width, double* sigma_out);
 
 /* ------------------------------------------------------------------------------------------------------
  * First downstream consumer of the moment matrix: the two streaming passes of

@@ -257,11 +257,11 @@ __global__ __launch_bounds__(128) void polar_profile_kernel(const double* __rest
 }
 
 // ---- exact k-th largest of non-negative doubles: radix select on the IEEE bit patterns, 16 bits per pass ----------
-__global__ __launch_bounds__(256) void radix_hist_kernel(const cplx* __restrict__ z, long long n, unsigned long long prefix,
-                                                         int shift, unsigned int* __restrict__ hist) {
+__global__ __launch_bounds__(256) void radix_hist_kernel(const double* __restrict__ v, int stride, long long n,
+                                                         unsigned long long prefix, int shift, unsigned int* __restrict__ hist) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
-  const unsigned long long key = (unsigned long long)__double_as_longlong(z[t].x);
+  const unsigned long long key = (unsigned long long)__double_as_longlong(v[t * stride]);
   if (shift < 48 && (key >> (shift + 16)) != prefix) return;
   atomicAdd(&hist[(key >> shift) & 0xffffu], 1u);
 }
@@ -296,6 +296,62 @@ __global__ __launch_bounds__(256) void to_complex_kernel(const T* __restrict__ i
 }
 
 inline unsigned blocks_of(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+// Bit pattern of the k-th largest (k >= 1) of n non-negative doubles v[0], v[stride], ... and the number of strictly
+// larger ones: radix select, four passes of 16-bit histograms (`d_hist`: 65536 counters on the device).
+int kth_largest(const double* d_v, int stride, long long n, long long k, unsigned int* d_hist, unsigned long long* key_out,
+                long long* above_out) {
+  unsigned long long prefix = 0;
+  long long above = 0;
+  std::vector<unsigned int> hist(65536);
+  for (int shift = 48; shift >= 0; shift -= 16) {
+    ZK_HIP(hipMemset(d_hist, 0, 65536 * 4));
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks_of(n)), dim3(256), 0, 0, d_v, stride, n, prefix, shift, d_hist);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpy(hist.data(), d_hist, 65536 * 4, hipMemcpyDeviceToHost));
+    int bin = 65535;
+    for (; bin > 0; --bin) {
+      if (above + (long long)hist[(size_t)bin] >= k) break;
+      above += hist[(size_t)bin];
+    }
+    prefix = (prefix << 16) | (unsigned long long)bin;
+  }
+  *key_out = prefix;
+  *above_out = above;
+  return 0;
+}
+
+// |dd| coefficients of a single-level db2 DWT with symmetric extension (PyWavelets dwtn(image, 'db2')['dd']):
+// out[i][j] = | sum_{a,b} h[a] h[b] ext(2 i + 1 + 3 - a, 2 j + 1 + 3 - b) |, ext = half-sample mirrored image
+template <typename T>
+__global__ __launch_bounds__(256) void db2_dd_kernel(const T* __restrict__ img, int H, int W, int oh, int ow, double* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)oh * ow) return;
+  const int i = (int)(t / ow), j = (int)(t - (long long)i * ow);
+  const double h[4] = {-0.48296291314469025, 0.836516303737469, -0.22414386804185735, -0.12940952255092145};
+  auto mirror = [](int e, int n) {  // index into the signal of position e of the extension (3 mirrored samples either side)
+    int q = e - 3;
+    if (q < 0) q = -1 - q;
+    if (q >= n) q = 2 * n - 1 - q;
+    return q < 0 ? 0 : (q >= n ? n - 1 : q);
+  };
+  double s = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int r = mirror(2 * i + 4 - a, H);
+    double rs = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) rs += h[b] * (double)img[(long long)r * W + mirror(2 * j + 4 - b, W)];
+    s += h[a] * rs;
+  }
+  out[t] = fabs(s);
+}
+
+__global__ __launch_bounds__(256) void count_nonzero_kernel(const double* __restrict__ v, long long n, unsigned long long* __restrict__ count) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long mask = __ballot(t < n && v[t] != 0.0);
+  if ((threadIdx.x & 63) == 0 && mask) atomicAdd(count, (unsigned long long)__popcll(mask));
+}
 
 int check_image(int dtype, int64_t H, int64_t W, const void* p) {
   if (dtype != ZK_F32 && dtype != ZK_F64) return zk_fail(ZK_E_BADARG, "dtype must be ZK_F32 or ZK_F64");
@@ -469,21 +525,8 @@ extern "C" int zk_denoise_fft(int device, const void* image_host, int dtype, int
   long long k = (long long)ceil(p * (double)n);
   k = k < 1 ? 1 : (k > n ? n : k);
   unsigned long long prefix = 0;
-  long long above = 0;  // elements strictly above the current prefix range
-  std::vector<unsigned int> hist(65536);
-  for (int shift = 48; shift >= 0; shift -= 16) {
-    ZK_HIP(hipMemset(d_hist.p, 0, 65536 * 4));
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks_of(n)), dim3(256), 0, 0, d_pow.as<cplx>(), n, prefix, shift,
-                       d_hist.as<unsigned int>());
-    ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpy(hist.data(), d_hist.p, 65536 * 4, hipMemcpyDeviceToHost));
-    int bin = 65535;
-    for (; bin > 0; --bin) {
-      if (above + (long long)hist[(size_t)bin] >= k) break;
-      above += hist[(size_t)bin];
-    }
-    prefix = (prefix << 16) | (unsigned long long)bin;
-  }
+  long long above = 0;
+  if ((rc = kth_largest((const double*)d_pow.p, 2, n, k, d_hist.as<unsigned int>(), &prefix, &above))) return rc;
   // `prefix` is now the bit pattern of the k-th largest power; `above` counts the strictly larger ones
   ZK_HIP(hipMemset(d_hist.p, 0, 4));
   hipLaunchKernelGGL(mask_kernel, dim3(blocks_of(n)), dim3(256), 0, 0, d_spec.as<cplx>(), d_pow.as<cplx>(), n, prefix,
@@ -493,5 +536,51 @@ extern "C" int zk_denoise_fft(int device, const void* image_host, int dtype, int
   hipLaunchKernelGGL(real_scale_kernel, dim3(blocks_of(n)), dim3(256), 0, 0, d_spec.as<cplx>(), 1.0 / (double)n, d_out.as<double>(), n);
   ZK_HIP(hipGetLastError());
   ZK_HIP(hipMemcpy(out_host, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// skimage.restoration.estimate_sigma for a 2-D image (restated, see mtflearn_amd/features/pickers.py): the median of the
+// non-zero |db2 diagonal detail coefficients| / 0.6745.  The coefficients and the two order statistics of the median are
+// computed on the device.
+extern "C" int zk_wavelet_sigma(int device, const void* image_host, int dtype, int64_t H, int64_t W, double* sigma_out) {
+  int rc = check_image(dtype, H, W, image_host);
+  if (rc) return rc;
+  if (!sigma_out) return zk_fail(ZK_E_BADARG, "null pointer");
+  if (H < 4 || W < 4) return zk_fail(ZK_E_BADARG, "image too small for a db2 decomposition (needs at least 4 x 4)");
+  ZK_ON_DEVICE(device);
+  const int oh = (int)((H + 3) / 2), ow = (int)((W + 3) / 2);
+  const long long n = (long long)oh * ow;
+  const size_t es = dtype == ZK_F32 ? 4 : 8;
+  dev_buf d_img, d_d, d_hist;
+  if ((rc = d_img.alloc((size_t)H * W * es)) || (rc = d_d.alloc((size_t)n * 8)) || (rc = d_hist.alloc(65536 * 4 + 8))) return rc;
+  ZK_HIP(hipMemcpy(d_img.p, image_host, (size_t)H * W * es, hipMemcpyHostToDevice));
+  if (dtype == ZK_F32)
+    hipLaunchKernelGGL(db2_dd_kernel<float>, dim3(blocks_of(n)), dim3(256), 0, 0, d_img.as<float>(), (int)H, (int)W, oh, ow, d_d.as<double>());
+  else
+    hipLaunchKernelGGL(db2_dd_kernel<double>, dim3(blocks_of(n)), dim3(256), 0, 0, d_img.as<double>(), (int)H, (int)W, oh, ow, d_d.as<double>());
+  ZK_HIP(hipGetLastError());
+  unsigned long long* d_count = (unsigned long long*)(d_hist.as<char>() + 65536 * 4);
+  ZK_HIP(hipMemset(d_count, 0, 8));
+  hipLaunchKernelGGL(count_nonzero_kernel, dim3(blocks_of(n)), dim3(256), 0, 0, d_d.as<double>(), n, d_count);
+  ZK_HIP(hipGetLastError());
+  unsigned long long m = 0;
+  ZK_HIP(hipMemcpy(&m, d_count, 8, hipMemcpyDeviceToHost));
+  if (m == 0) {  // numpy: median of an empty array is NaN
+    *sigma_out = NAN;
+    return 0;
+  }
+  // numpy.median of the m non-zero values (the zeros are the smallest keys, so ranks among the largest are unaffected):
+  // the (m + 1) / 2-th largest for odd m, the mean of the m / 2-th and the (m / 2 + 1)-th largest for even m
+  unsigned long long key = 0;
+  long long above = 0;
+  double lo, hi;
+  if ((rc = kth_largest(d_d.as<double>(), 1, n, (long long)(m / 2 + 1), d_hist.as<unsigned int>(), &key, &above))) return rc;
+  memcpy(&lo, &key, 8);
+  hi = lo;
+  if (m % 2 == 0) {
+    if ((rc = kth_largest(d_d.as<double>(), 1, n, (long long)(m / 2), d_hist.as<unsigned int>(), &key, &above))) return rc;
+    memcpy(&hi, &key, 8);
+  }
+  *sigma_out = 0.5 * (lo + hi) / 0.6744897501960817;
   return 0;
 }

@@ -78,6 +78,7 @@ SYMBOLS = {
     "zk_power_spectra": (c_int, [c_int, c_void_p, c_int, c_int64, c_int64, c_int64, POINTER(c_int32), c_int,
                                  POINTER(c_double), POINTER(c_double)]),
     "zk_denoise_fft": (c_int, [c_int, c_void_p, c_int, c_int64, c_int64, c_double, POINTER(c_double)]),
+    "zk_wavelet_sigma": (c_int, [c_int, c_void_p, c_int, c_int64, c_int64, POINTER(c_double)]),
     "zk_gram": (c_int, [c_int, POINTER(c_double), c_int64, c_int, POINTER(c_double), POINTER(c_void_p)]),
     "zk_project": (c_int, [c_int, c_void_p, c_int64, c_int, POINTER(c_double), POINTER(c_double), c_int, POINTER(c_double),
                            c_int]),

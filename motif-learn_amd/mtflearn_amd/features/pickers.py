@@ -10,7 +10,7 @@ What runs where.  The array work goes through ``libzernike_hip.so`` (``zk_autoco
 ``zk_power_spectra``, ``zk_denoise_fft``: hipFFT transforms with hand-written kernels around them, see
 ``csrc/zk_pickers.hip``); there is no CPU fallback.  The 1-D tails -- Gaussian smoothing + ``scipy.signal.find_peaks``
 on a profile of a few hundred samples, cumulative sums, the median of the per-patch estimates -- are the reference's
-own NumPy / SciPy calls on the host, as is the wavelet noise estimate (a few filter passes, once per image).
+own NumPy / SciPy calls on the host.
 
 Parity status: ``_patch_size.py`` and ``_estimate_n_max.py`` import scikit-image, which is not installed
 in the build image, and two of their steps ARE scikit-image calls -- ``skimage.transform.warp_polar`` (inside
@@ -188,34 +188,22 @@ def denoise_fft(image, p):
 
 
 # ------------------------------------------------------------------------------------------ _estimate_n_max.py
-_DB2_HI = np.array([-0.48296291314469025, 0.836516303737469, -0.22414386804185735, -0.12940952255092145])
-
-
-def _dwt_high_symmetric(x, axis):
-    """Detail coefficients of a single-level ``db2`` DWT along ``axis`` with PyWavelets' default 'symmetric'
-    (half-sample) extension: full convolution of the extended signal with the decomposition high-pass filter, odd
-    samples kept -- output length ``(n + 3) // 2``."""
-    x = np.moveaxis(np.asarray(x, dtype=np.float64), axis, -1)
-    n, f = x.shape[-1], len(_DB2_HI)
-    ext = np.concatenate([x[..., f - 2::-1], x, x[..., :-f:-1]], axis=-1)        # f-1 mirrored samples either side
-    n_out = (n + f - 1) // 2
-    out = np.zeros(x.shape[:-1] + (n_out,))
-    for k in range(f):
-        # conv_valid[j] = sum_k h[k] ext[j + f - 1 - k];  c[i] = conv_valid[2 i + 1]
-        start = 1 + f - 1 - k
-        out += _DB2_HI[k] * ext[..., start:start + 2 * n_out:2]
-    return np.moveaxis(out, -1, axis)
-
-
 def estimate_sigma(image):
     """Robust wavelet estimate of the Gaussian noise standard deviation of a 2-D image:
-    ``skimage.restoration.estimate_sigma`` (median absolute ``db2`` diagonal detail coefficient / 0.6745).
-    Restated from scikit-image / PyWavelets (not installed here): **parity-unpinned**; it only decides which branch
-    ``estimate_n_max`` takes (``sigma > t``)."""
-    image = np.asarray(image, dtype=np.float64)
-    detail = _dwt_high_symmetric(_dwt_high_symmetric(image, 0), 1)
-    detail = detail[np.nonzero(detail)]
-    return float(np.median(np.abs(detail)) / 0.6744897501960817)
+    ``skimage.restoration.estimate_sigma`` (median absolute ``db2`` diagonal detail coefficient / 0.6745), on the device
+    (``zk_wavelet_sigma``).  Restated from scikit-image / PyWavelets (not installed here): **parity-unpinned**; it only
+    decides which branch ``estimate_n_max`` takes (``sigma > t``)."""
+    lib = _native.load()
+    if _native.device_count() == 0:
+        raise RuntimeError("no HIP device visible: mtflearn_amd computes on MI355X only (there is no CPU fallback)")
+    img = _operand(image)
+    if img.ndim != 2:
+        raise ValueError("estimate_sigma needs a 2-D image")
+    from ctypes import byref
+    sigma = c_double()
+    _call(lib.zk_wavelet_sigma(_device(), img.ctypes.data_as(c_void_p), _native.dtype_code(img.dtype), img.shape[0], img.shape[1],
+                               byref(sigma)), "zk_wavelet_sigma")
+    return float(sigma.value)
 
 
 def add_gaussian_noise(img, sigma=0.1, seed=None):

@@ -121,3 +121,15 @@ def test_estimate_n_max_end_to_end(pg, po, pk):
         assert 12 <= got <= 16
     got = pk.estimate_n_max_from_patch(pg["noisy_192"][:64, :64].astype(np.float64), p=0.05)
     assert 12 <= got <= 32
+
+
+def test_wavelet_sigma_device_equals_oracle(pg, po, pk):
+    rng = np.random.default_rng(1)
+    for shape in ((64, 64), (65, 37), (192, 192), (4, 5), (511, 300)):
+        x = rng.standard_normal(shape)
+        assert abs(pk.estimate_sigma(x) - po.estimate_sigma(x)) < 1e-13, shape
+    assert abs(pk.estimate_sigma(pg["noisy_192"]) - po.estimate_sigma(pg["noisy_192"])) < 1e-9     # float32 image
+    sparse = np.zeros((64, 64))
+    sparse[10:20, 30:41] = rng.standard_normal((10, 11))                      # most coefficients exactly zero: they are dropped
+    assert abs(pk.estimate_sigma(sparse) - po.estimate_sigma(sparse)) < 1e-13
+    assert np.isnan(pk.estimate_sigma(np.zeros((16, 16))))
