@@ -237,3 +237,32 @@ def test_detector_formats_are_widened_on_the_device(dt):
         for key in ("rot_maps", "abs", "mirror_map"):
             np.testing.assert_array_equal(a[key], b[key])
     plan.set_host_chunk(0)
+
+
+@pytest.mark.parametrize("rendezvous", ["file", "tcp"])
+def test_two_process_rendezvous_reaches_rccl(tmp_path, rendezvous):
+    """Two real processes meet through the file / TCP rendezvous of zk_comm_init_*: both receive rank 0's id and enter
+    ncclCommInitRank.  On this one-GPU box RCCL then refuses the communicator (both ranks sit on device 0) -- which is
+    exactly what shows that the id travelled: a broken rendezvous would time out or fail to connect instead."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys; sys.path.insert(0, sys.argv[1]);\n"
+        "from mtflearn_amd import _native\n"
+        "rank = int(sys.argv[2]); kw = dict(path=sys.argv[4]) if sys.argv[3] == 'file' else dict(port=int(sys.argv[4]))\n"
+        "try:\n"
+        "    _native.Comm(0, rank, 2, timeout=60.0, **kw)\n"
+        "    print('CONNECTED')\n"
+        "except RuntimeError as exc:\n"
+        "    print('ERROR', exc)\n")
+    target = str(tmp_path / "id") if rendezvous == "file" else "29655"
+    procs = [subprocess.Popen([sys.executable, "-c", code, os.path.join(ROOT, "motif-learn_amd"), str(r), rendezvous, target],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for out in outs:
+        assert "timed out" not in out and "cannot" not in out, outs
+        # two ranks on one device: RCCL rejects the communicator (or, on a multi-GPU box, would accept it)
+        assert "CONNECTED" in out or "ncclCommInitRank" in out, outs
+    if rendezvous == "file":
+        assert not os.path.exists(target)
