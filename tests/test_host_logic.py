@@ -321,3 +321,29 @@ def test_container_matches_oracle_on_random_moments(seed):
     np.testing.assert_allclose(zm.normalize(order=p).data, zo.normalize(data, order=p), rtol=1e-14)
     if data.ndim == 3:
         np.testing.assert_array_equal(zm.valid_mask, zo.valid_mask(data.shape[1:], 9))
+
+
+def test_pca_host_arithmetic_matches_sklearn():
+    """The host half of the device pca (covariance from the Gram matrix, eigh, ordering, sign convention) against
+    scikit-learn's PCA -- the reference's pca() is PCA(n).fit_transform(X) (features/_dimension_reduction.py:3-6).
+    The two device passes (zk_gram, zk_project) are stood in for by NumPy here; tests/test_gpu_consumers.py runs them."""
+    from sklearn.decomposition import PCA
+    from mtflearn_amd.features.consumers import _covariance_eigh
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((3000, 45)) * rng.random(45) * 2 + rng.random(45)
+    aug = np.hstack([X, np.ones((X.shape[0], 1))])
+    mean, vt, var = _covariance_eigh(aug.T @ aug, X.shape[0])
+    model = PCA(n_components=6).fit(X)
+    np.testing.assert_allclose(mean, model.mean_, rtol=1e-12)
+    np.testing.assert_allclose(vt[:6], model.components_, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(var[:6], model.explained_variance_, rtol=1e-9)
+    np.testing.assert_allclose((X - mean) @ vt[:6].T, model.transform(X), rtol=0, atol=1e-9)
+
+
+def test_pinned_pool_disabled_hands_out_plain_arrays(monkeypatch):
+    monkeypatch.setenv("MTFLEARN_AMD_PINNED_MB", "0")
+    pool = _native.PinnedPool()
+    a = pool.empty((1024, 1024))
+    assert a.flags.owndata and a.shape == (1024, 1024) and a.dtype == np.float64
+    small = _native.PinnedPool().empty((4, 4))            # below the size where a pinned block pays off
+    assert small.flags.owndata
