@@ -181,8 +181,9 @@ def test_strided_grid_matches_reference_extractor(native, zo):
 
 
 def test_fused_symmetry_maps(native, golden, zo):
-    """Fused frame -> maps kernel against the reference's tail on the golden frame and against the
-    host container composed with the device transform on random frames (all option combinations)."""
+    """Fused frame -> maps kernel against the reference's tail on the golden frame; on random frames against the oracle
+    (oracle moments through the oracle's tail) and, for all option combinations, against the host container composed with
+    the device transform."""
     z = _zps(6, 12)
     img = golden["frame_f32_24_28"]
     maps = z.symmetry_maps(img)
@@ -203,6 +204,17 @@ def test_fused_symmetry_maps(native, golden, zo):
         zz = _zps(n_max, size)
         frame = (rng.random(shape) + 0.1).astype(dtype)
         zm = zz.transform(frame)
+        # independent of the product: the oracle's moments of this frame through the oracle's restatement of the
+        # reference tail (_zmoments.py:300-316, 420-493)
+        o_mom = zo.moments_frame_direct(frame, zz.polynomials)
+        floor = 3e-6 if n_max > 20 else 1e-7 if n_max > 16 else 1e-9 if n_max > 12 else 1e-10
+        for kw in (dict(), dict(n_folds=[2, 5], m_unselect=(0, 2), p=None, theta=np.linspace(0, 2 * np.pi, 48, endpoint=False))):
+            got = zz.symmetry_maps(frame, **kw)
+            folds, unsel, pp = kw.get("n_folds", [2, 3, 4, 6]), kw.get("m_unselect", (0, 1)), kw.get("p", 2)
+            rel_close(got["rot_maps"], zo.rot_maps(o_mom, zz.n, zz.m, list(folds), p=pp, m_unselect=unsel), rtol=1e-6, atol_scale=floor)
+            rel_close(got["abs"], np.abs(zo.to_complex(o_mom, zz.n, zz.m)[0]), rtol=1e-6, atol_scale=floor)
+            rel_close(got["mirror_map"], zo.mirror_map(o_mom, zz.n, zz.m, theta=kw.get("theta"), p=pp, m_unselect=unsel),
+                      rtol=1e-6, atol_scale=floor)
         for kwargs in [dict(), dict(n_folds=[3], p=None), dict(n_folds=[2, 3, 4, 5, 6, 8], m_unselect=(0, 1, 2)),
                        dict(n_folds=None, abs_moments=False), dict(mirror=False, n_folds=[1, 2]),
                        dict(theta=np.linspace(0, np.pi, 37))]:
