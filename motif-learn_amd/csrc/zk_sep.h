@@ -265,46 +265,58 @@ struct zk_sep_rows {
   template <bool FIRST, typename PX>
   __device__ __forceinline__ void row_pixel(double a, double b, const PX& px) {
     const double s = a + b, d = a - b;
+    if constexpr (kEE || kEO) {  // even x degrees (a wave of a pair kernel owns one x parity, zk_sep_patches.hip)
 #pragma unroll
-    for (int i = 0; i < S::NE; ++i) {
-      if (FIRST) SEp[i] = __builtin_fma(s, px[2 * i], SEp[i]);
-      else SEm[i] = __builtin_fma(s, px[2 * i], SEm[i]);
+      for (int i = 0; i < S::NE; ++i) {
+        if (FIRST) SEp[i] = __builtin_fma(s, px[2 * i], SEp[i]);
+        else SEm[i] = __builtin_fma(s, px[2 * i], SEm[i]);
+      }
     }
+    if constexpr (kOE || kOO) {
 #pragma unroll
-    for (int i = 0; i < S::NO; ++i) {
-      if (FIRST) SOp[i] = __builtin_fma(d, px[2 * i + 1], SOp[i]);
-      else SOm[i] = __builtin_fma(d, px[2 * i + 1], SOm[i]);
+      for (int i = 0; i < S::NO; ++i) {
+        if (FIRST) SOp[i] = __builtin_fma(d, px[2 * i + 1], SOp[i]);
+        else SOm[i] = __builtin_fma(d, px[2 * i + 1], SOm[i]);
+      }
     }
   }
   // the same with P_0 = 1 implicit: p1[a - 1] = P_a(x_c), a = 1 .. NMAX (even patch sizes: no half-weight column)
   template <bool FIRST, typename PX>
   __device__ __forceinline__ void row_pixel_p0(double a, double b, const PX& p1) {
     const double s = a + b, d = a - b;
-    if (FIRST) SEp[0] += s;
-    else SEm[0] += s;
+    if constexpr (kEE || kEO) {
+      if (FIRST) SEp[0] += s;
+      else SEm[0] += s;
 #pragma unroll
-    for (int i = 1; i < S::NE; ++i) {
-      if (FIRST) SEp[i] = __builtin_fma(s, p1[2 * i - 1], SEp[i]);
-      else SEm[i] = __builtin_fma(s, p1[2 * i - 1], SEm[i]);
+      for (int i = 1; i < S::NE; ++i) {
+        if (FIRST) SEp[i] = __builtin_fma(s, p1[2 * i - 1], SEp[i]);
+        else SEm[i] = __builtin_fma(s, p1[2 * i - 1], SEm[i]);
+      }
     }
+    if constexpr (kOE || kOO) {
 #pragma unroll
-    for (int i = 0; i < S::NO; ++i) {
-      if (FIRST) SOp[i] = __builtin_fma(d, p1[2 * i], SOp[i]);
-      else SOm[i] = __builtin_fma(d, p1[2 * i], SOm[i]);
+      for (int i = 0; i < S::NO; ++i) {
+        if (FIRST) SOp[i] = __builtin_fma(d, p1[2 * i], SOp[i]);
+        else SOm[i] = __builtin_fma(d, p1[2 * i], SOm[i]);
+      }
     }
   }
   __device__ __forceinline__ void pair_combine() {
+    if constexpr (kEE || kEO) {
 #pragma unroll
-    for (int i = 0; i < S::NE; ++i) {
-      const double t = SEp[i];
-      SEp[i] = t + SEm[i];
-      SEm[i] = t - SEm[i];
+      for (int i = 0; i < S::NE; ++i) {
+        const double t = SEp[i];
+        SEp[i] = t + SEm[i];
+        SEm[i] = t - SEm[i];
+      }
     }
+    if constexpr (kOE || kOO) {
 #pragma unroll
-    for (int i = 0; i < S::NO; ++i) {
-      const double t = SOp[i];
-      SOp[i] = t + SOm[i];
-      SOm[i] = t - SOm[i];
+      for (int i = 0; i < S::NO; ++i) {
+        const double t = SOp[i];
+        SOp[i] = t + SOm[i];
+        SOm[i] = t - SOm[i];
+      }
     }
   }
 };
@@ -416,6 +428,15 @@ struct zk_sep_acc : zk_sep_rows<NMAX, MASK> {
   }
 };
 
+template <typename F, int... Is>
+__device__ __forceinline__ void zk_for_each_slot_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void zk_for_each_slot(F&& f) {
+  zk_for_each_slot_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // Epilogue of the batch kernels: the wave's 64 x N_poly moments (lane = patch, z in class-ordered
 // slots) become rows of the (N, n_poly) output through a 16-KiB LDS slab and leave as contiguous
 // 16-B-per-lane non-temporal stores.  ppp = patches per pass (host: largest power of two with
@@ -463,6 +484,51 @@ __device__ __forceinline__ void zk_batch_store_rows(const double (&z)[NP], const
 #endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next pass overwrites
+  }
+}
+
+// The same for the pair kernels (zk_sep_patches.hip): the two waves of a pair hold the moments of the SAME 64 patches,
+// each the columns of its x parity (MASK); both stage their columns into the pair's shared slab, then share the stores.
+// Workgroup barriers order the two phases (every wave of the workgroup runs the same number of passes).
+template <int NMAX, int MASK, int NP>
+__device__ __forceinline__ void zk_batch_store_rows_pair(const double (&z)[NP], const ZK_CONST int32_t* cmap, double* slab,
+                                                         double* obase, int lane, int part, int nv, int n_poly, int ppp) {
+  using S = zk_sep_set<NMAX>;
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  const int mis = (int)(((uintptr_t)obase >> 3) & 1);
+#pragma unroll 1
+  for (int h = 0; h * ppp < 64; ++h) {
+    if (lane / ppp == h) {
+      double* const row = slab + mis + (lane % ppp) * n_poly;
+      zk_for_each_slot<NP>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        constexpr int cls = i < S::cls_begin(1) ? 0 : i < S::cls_begin(2) ? 1 : i < S::cls_begin(3) ? 2 : 3;
+        if constexpr ((MASK >> cls) & 1) {
+          const int col = cmap[i];
+          if (col >= 0) row[col] = z[i];
+        }
+      });
+    }
+    __syncthreads();  // both waves' columns are in the slab
+    int live = nv - h * ppp;
+    live = live < 0 ? 0 : (live > ppp ? ppp : live);
+    const int vd = live * n_poly;
+    double* const dst = obase + (long long)h * ppp * n_poly;
+    for (int k = lane + 64 * part; 2 * k < vd + mis; k += 128) {
+      const f64x2 v = *(const f64x2*)(slab + 2 * k);
+      const int e = 2 * k - mis;
+      if (e >= 0 && e + 2 <= vd) {
+#if ZK_STORE_NT
+        __builtin_nontemporal_store(v, (f64x2*)(dst + e));
+#else
+        *(f64x2*)(dst + e) = v;
+#endif
+      } else {
+        if (e >= 0 && e < vd) dst[e] = v.x;
+        if (e + 1 >= 0 && e + 1 < vd) dst[e + 1] = v.y;
+      }
+    }
+    __syncthreads();  // slab reads done before the next pass overwrites
   }
 }
 

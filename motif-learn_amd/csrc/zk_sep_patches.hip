@@ -87,12 +87,17 @@ namespace {
 // MASK: the parity classes this launch computes -- all of them (15), or one class per launch for
 // n_max > 16 (zk_sep.h); a class pass writes its moments as planes of a scratch matrix [column][patch]
 // (coalesced over the lanes), which zk_transpose_kernel turns into the (N, n_poly) rows afterwards.
-template <int NMAX, int RUN, typename TIN, bool WIDE, int MASK = 15>
-__global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1)) void zk_patch_sep_kernel(
+// PAIR: two waves share one group of 64 patches and one pair of LDS slabs; each keeps the accumulators of ONE x parity
+// (MASK = EE|EO or OE|OO: T is block-diagonal in the parity classes, so the halves never meet before the output row).
+// The instances whose full accumulator set needs 300-460 registers (n_max 11-16: one wave per SIMD, 28-60 % of the
+// HBM peak) fit two waves per SIMD this way: the DMA of a unit is issued half by each wave, every byte still crosses
+// HBM once, the LDS slab is read by both.  Two workgroup barriers per unit order landing -> reading -> re-arming.
+template <int NMAX, int RUN, typename TIN, bool WIDE, int MASK, bool PAIR>
+__device__ __forceinline__ void zk_patch_body(
     const TIN* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
     const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
     int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp, const int32_t* __restrict__ row_starts,
-    int n_row_starts, const double* __restrict__ pfull) {
+    int n_row_starts, const double* __restrict__ pfull, float* const wl, const long long group, const int part) {
   using S = zk_sep_set<NMAX>;
   constexpr int PXG = 16 / sizeof(TIN);  // pixels per 16-B granule: 4 (float32) or 2 (float64)
   typedef TIN gran_t __attribute__((ext_vector_type(PXG)));
@@ -102,37 +107,38 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
   // nt only where a run is a whole 128-B line: 64-B runs share their line with another unit of the same
   // row, which must still find it in L2 (default policy: 3.70 -> 2.14 ms at K=16, 8.9 -> 6.0 ms at K=48)
   constexpr int DMA_AUX = RUN == 8 ? ZK_DMA_AUX : 0;
-  constexpr int DEPTH = ZK_BATCH_DEPTH(NMAX, MASK);
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // DEPTH slabs of 16 KiB per wave
+  constexpr int DEPTH = PAIR ? 2 : ZK_BATCH_DEPTH(NMAX, MASK);  // slabs of 16 KiB (per wave, or per pair)
+  constexpr int NDMA = PAIR ? 8 : 16;                           // DMA instructions this wave issues per unit
 
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* const wl = lds + wave * (4096 * DEPTH);
-  const long long patch0 = ((long long)blockIdx.x * 4 + wave) * 64;
-  if (patch0 >= n_patches) return;  // wave-uniform; the kernel has no workgroup barrier
+  const long long patch0 = group * 64;
+  // single-wave form: a wave without patches leaves (the kernel has no barrier).  Pair form: every wave of the
+  // workgroup runs the whole loop (barriers); a pair without patches reads patch 0 of the batch and stores nothing.
+  if (!PAIR && patch0 >= n_patches) return;
   const long long left = n_patches - patch0;
-  const int nv = left < 64 ? (int)left : 64;  // live patches of this wave
+  const int nv = left <= 0 ? 0 : (left < 64 ? (int)left : 64);  // live patches of this wave / pair
 
   // ---- DMA addressing: lane -> (patch-in-group a, slot b) ---------------------------------------
   const int a = lane / RUN, b = lane % RUN;
   const int g0 = (b - (a >> SH)) & (RUN - 1);  // source granule for patch group 0
-  const char* const wbase = (const char*)in + patch0 * patch_bytes;
+  const char* const wbase = (const char*)in + (nv > 0 ? patch0 : 0) * patch_bytes;
   int poff[RUN];  // per patch group: byte offset of this lane's patch (+ its rotated granule)
 #pragma unroll
   for (int pg = 0; pg < RUN; ++pg) {
     int pi = pg * PPI + a;
-    pi = pi < nv ? pi : nv - 1;  // tail wave: re-read the last live patch
+    pi = pi < nv ? pi : (nv > 0 ? nv - 1 : 0);  // tail wave: re-read the last live patch
     // rot(patch) = (pg*PPI + a) >> SH = 4*pg + (a >> SH) for both RUN values
     const int g = (g0 - 4 * pg) & (RUN - 1);
     poff[pg] = pi * patch_bytes + g * 16;
   }
   const ZK_CONST int32_t* utab = zk_const((const int32_t*)units);  // 8 ints per unit
-  auto issue = [&](int u, float* slab) {  // 16 DMA instructions: one unit into one slab
+  auto issue = [&](int u, float* slab) {  // one unit into one slab: 16 DMA instructions (a pair: 8 from each wave)
 #pragma unroll
     for (int rho = 0; rho < NRUN; ++rho) {
       const int ro = utab[8 * u + rho];
 #pragma unroll
       for (int pg = 0; pg < RUN; ++pg) {
+        if (PAIR && (pg < RUN / 2) != (part == 0)) continue;  // wave-uniform: this wave's half of the patch groups
         __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(wbase + (poff[pg] + ro)),
                                          ZK_LDS_PTR(slab + (rho * RUN + pg) * 256), 16, 0, DMA_AUX);
       }
@@ -151,9 +157,7 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
 
   // first unit of this wave (see ZK_ROTATE): the start of some row pair; the loop visits off, off+1, ...,
   // wrapping around, so the units of a row stay consecutive
-  const int off = n_row_starts > 0
-                      ? zk_const(row_starts)[(int)((((long long)blockIdx.x * 4 + wave) * 7) % n_row_starts)]
-                      : 0;
+  const int off = n_row_starts > 0 ? zk_const(row_starts)[(int)((group * 7) % n_row_starts)] : 0;
   auto unit_at = [&](int k) { return k + off < n_units ? k + off : k + off - n_units; };
 #if ZK_ABLATE != 2
   issue(unit_at(0), wl);
@@ -167,8 +171,13 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
     float* const ws = DEPTH == 2 ? wl + (k & 1) * 4096 : wl;  // wave-uniform: the slab unit k landed in
     // this wave's DMA of unit u has landed (loads complete in order: with a second unit in flight, all but its
     // 16 instructions)
-    if (DEPTH == 2 && k + 1 < n_units) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DEPTH == 2 && k + 1 < n_units) {
+      if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if constexpr (PAIR) __syncthreads();  // the partner's half of the unit has landed too
     // The unit is consumed in two halves of 8 quadrant pixels so that only 32 staging VGPRs are live:
     // the outer half first (quadrant columns c0..c0+7, often entirely outside the disk and then not even
     // read), then the inner half; the slab is re-armed as soon as the inner half is in registers.
@@ -194,6 +203,7 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
       }
       if (rearm) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // unit is in VGPRs: the slab may be re-armed
+        if constexpr (PAIR) __syncthreads();                  // ... once the partner has read it too
 #if ZK_ABLATE != 2
         if (k + DEPTH < n_units) issue(unit_at(k + DEPTH), ws);
 #endif
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
       }
       if (rearm) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (PAIR) __syncthreads();
 #if ZK_ABLATE != 2
         if (k + DEPTH < n_units) issue(unit_at(k + DEPTH), ws);
 #endif
@@ -309,7 +320,13 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
   }
 
   const ZK_CONST int32_t* cmap = zk_const(colmap);
-  if constexpr (MASK == 15) {
+  if constexpr (PAIR) {
+    // ---- Z = T M for this wave's classes; the pair assembles the output rows in its shared slab -----------------
+    double z[S::NP];
+    acc.transform(zk_const(tmat), [&](auto slot, double v) { z[slot] = v; });
+    zk_batch_store_rows_pair<NMAX, MASK, S::NP>(z, cmap, (double*)wl, out + (nv > 0 ? patch0 : 0) * n_poly, lane, part, nv, n_poly,
+                                                ppp);
+  } else if constexpr (MASK == 15) {
     // ---- Z = T M, then (patch, column) rows via LDS -> 16-B stores ----------------------------------
     double z[S::NP];
     acc.transform(zk_const(tmat), [&](auto slot, double v) { z[slot] = v; });
@@ -323,6 +340,42 @@ __global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1))
       if (col >= 0 && lane < nv) sp[(long long)col * n_patches] = v;
     });
   }
+}
+
+template <int NMAX, int RUN, typename TIN, bool WIDE, int MASK = 15>
+__global__ __launch_bounds__(256, ((NMAX <= ZK_BATCH_2W || MASK != 15) ? 2 : 1)) void zk_patch_sep_kernel(
+    const TIN* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
+    const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
+    int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp, const int32_t* __restrict__ row_starts,
+    int n_row_starts, const double* __restrict__ pfull) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // DEPTH slabs of 16 KiB per wave
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  zk_patch_body<NMAX, RUN, TIN, WIDE, MASK, false>(in, out, units, xq, tmat, colmap, n_units, n_poly, n_patches, patch_bytes, ppp,
+                                                    row_starts, n_row_starts, pfull,
+                                                    lds + wave * (4096 * ZK_BATCH_DEPTH(NMAX, MASK)),
+                                                    (long long)blockIdx.x * 4 + wave, 0);
+}
+
+// pair form: 4 waves = 2 pairs per workgroup, 2 x 2 slabs of 16 KiB; two workgroups per CU (8 waves, 128 KiB)
+template <int NMAX, int RUN, typename TIN, bool WIDE>
+__global__ __launch_bounds__(256, 2) void zk_patch_pair_kernel(
+    const TIN* __restrict__ in, double* __restrict__ out, const zk_sep_unit* __restrict__ units,
+    const double* __restrict__ xq, const double* __restrict__ tmat, const int32_t* __restrict__ colmap,
+    int n_units, int n_poly, long long n_patches, int patch_bytes, int ppp, const int32_t* __restrict__ row_starts,
+    int n_row_starts, const double* __restrict__ pfull) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = wave >> 1;
+  float* const wl = lds + pair * 8192;
+  const long long group = (long long)blockIdx.x * 2 + pair;
+  if ((wave & 1) == 0)
+    zk_patch_body<NMAX, RUN, TIN, WIDE, (1 << ZK_EE) | (1 << ZK_EO), true>(in, out, units, xq, tmat, colmap, n_units, n_poly, n_patches,
+                                                                            patch_bytes, ppp, row_starts, n_row_starts, pfull, wl,
+                                                                            group, 0);
+  else
+    zk_patch_body<NMAX, RUN, TIN, WIDE, (1 << ZK_OE) | (1 << ZK_OO), true>(in, out, units, xq, tmat, colmap, n_units, n_poly, n_patches,
+                                                                            patch_bytes, ppp, row_starts, n_row_starts, pfull, wl,
+                                                                            group, 1);
 }
 
 // in[c * n + p] -> out[p * n_poly + c]: the class passes' scratch planes to (N, n_poly) rows
@@ -348,6 +401,26 @@ int launch_one(zk_plan* p, const void* in, int64_t n_patches, double* out, hipSt
   if (blocks > 0x7fffffffLL) return zk_fail(ZK_E_BADARG, "too many patches for one launch");
   int ppp = 64;
   while (ppp * p->n_poly > 2048) ppp >>= 1;
+  if constexpr (MASK == 15 && (NMAX > ZK_BATCH_2W)) {
+    // n_max 11-16.  Row-pair units (sizes whose rows are not whole 128-B lines twice over): the pair kernel -- two waves per
+    // SIMD instead of one: (32, 12) 4.70 -> 5.39 TB/s, (32, 14) 3.96 -> 4.78, (32, 16) 2.66 -> 3.43, (40, 12) 3.65 -> 3.88.
+    // Wide units (float32 K % 64 == 0, float64 K % 32 == 0) stay on the one-wave kernel with its pipelined scalar loads,
+    // where each wave of a pair would use half of every Legendre row it fetches: (128, 12) 6.18 vs 5.30, (64, 16) 3.53 vs
+    // 2.93 (profiles/r02_batch_sweep.txt).  ZK_BATCH_PAIR=0 / 1 in the environment forces one form (A/B runs).
+    static const char* const force = getenv("ZK_BATCH_PAIR");
+    const bool use_pair = force ? force[0] != '0' : !WIDE;
+    if (use_pair) {
+      auto pk = zk_patch_pair_kernel<NMAX, RUN, TIN, WIDE>;
+      const long long pblocks = (waves + 1) / 2;
+      int rc = zk_prof_begin(p, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(pk, dim3((unsigned)pblocks), dim3(256), 65536, s, (const TIN*)in, out, bt.d_units, t->d_xq, t->d_T,
+                         t->d_colmap, bt.n_units, p->n_poly, (long long)n_patches, p->size * p->size * (int)sizeof(TIN), ppp,
+                         bt.d_row_starts, ZK_ROTATE ? bt.n_row_starts : 0, t->d_pfull);
+      ZK_HIP(hipGetLastError());
+      return zk_prof_end(p, s);
+    }
+  }
   auto kern = zk_patch_sep_kernel<NMAX, RUN, TIN, WIDE, MASK>;
   const size_t lds = (size_t)4 * ZK_BATCH_DEPTH(NMAX, MASK) * 16384;
   if (lds > 64 * 1024)
