@@ -61,7 +61,7 @@ __device__ __forceinline__ void zk_for_each_int(F&& f, std::integer_sequence<int
 // The symmetry-map tail shared by the fused kernel (moments from the T product in registers) and the
 // planes kernel (moments from a (N_poly, rows, W) matrix in memory): `get(n, |m|, A, B)` delivers the
 // complex moment A + iB = Z_{n,+m} + i Z_{n,-m} of this lane's pixel.  `pix` / `plane` address the outputs.
-template <int NMAX, typename GET>
+template <int NMAX, bool BY_ORDER = false, typename GET>
 __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& prm, const double* __restrict__ trig,
                                              bool live, long long plane, long long pix, double* __restrict__ rot_out,
                                              double* __restrict__ abs_out, double* __restrict__ mirror_out) {
@@ -82,16 +82,42 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
     Sm[am] = __builtin_fma(2.0 * A, B, Sm[am]);
   };
 
-  // +m and -m of one (n, |m|) are produced back to back (they live in partner parity classes of the T
-  // product) and folded into the running sums at once, so no moment outlives its own combine().
-  zk_for_each_int(
-      [&](auto k) {
-        constexpr int n = Z::complex_n(decltype(k)::value), am = Z::complex_m(decltype(k)::value);
-        double A, B = 0.0;
-        get(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
-        combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
-      },
-      std::make_integer_sequence<int, Z::NC>{});
+  if constexpr (BY_ORDER) {
+    // Moments that come from memory (planes kernel, n_max 17-24).  Written out per (n, |m|) at compile time -- 231
+    // combine bodies at n_max 20, each with its double-precision square-root expansion -- the kernel needed 512 registers
+    // plus 640 spilled (2.2 KB of scratch per lane) and ran at 0.3 TB/s.  Here the order n is a RUN-TIME loop and only
+    // |m| is unrolled: an order's 2 (NMAX + 1) loads are issued together, unconditionally (slots that do not exist for
+    // this n re-read plane 0 and are ignored), then folded under wave-uniform tests.
+    for (int n = 0; n <= prm.plan_nmax; ++n) {
+      double A[NMAX + 1], B[NMAX + 1];
+#pragma unroll
+      for (int am = 0; am <= NMAX; ++am) {
+        const bool valid = am <= n && ((n - am) & 1) == 0;
+        get(n, am, valid, A[am], B[am]);
+      }
+#pragma unroll
+      for (int am = 0; am <= NMAX; ++am) {
+        if (am <= n && ((n - am) & 1) == 0) {  // wave-uniform
+          const double a2 = A[am] * A[am], b2 = B[am] * B[am];
+          if (abs_out != nullptr && live) abs_out[Z::complex_index(n, am) * plane + pix] = __builtin_sqrt(a2 + b2);
+          Em[am] += a2 + b2;
+          Cm[am] += a2 - b2;
+          Sm[am] = __builtin_fma(2.0 * A[am], B[am], Sm[am]);
+        }
+      }
+    }
+  } else {
+    // +m and -m of one (n, |m|) are produced back to back (they live in partner parity classes of the T
+    // product) and folded into the running sums at once, so no moment outlives its own combine().
+    zk_for_each_int(
+        [&](auto k) {
+          constexpr int n = Z::complex_n(decltype(k)::value), am = Z::complex_m(decltype(k)::value);
+          double A, B = 0.0;
+          get(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
+          combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
+        },
+        std::make_integer_sequence<int, Z::NC>{});
+  }
 
   // drop the unselected |m| (wave-uniform mask), then the per-pixel scalar ||Z_sel||^2
   double norm2 = 0.0;
@@ -297,15 +323,12 @@ __global__ __launch_bounds__(256) void zk_maps_planes_kernel(const double* __res
   const bool live = t < mplane;
   const long long mp = live ? t : 0;
   const long long pix = mp + (long long)out_row0 * W;
-  zk_maps_tail<NMAX>(
-      [&](auto nn, auto amm, double& A, double& B) {
-        constexpr int n = decltype(nn)::value, am = decltype(amm)::value;
-        if (n <= prm.plan_nmax) {  // wave-uniform: planes above the plan's n_max do not exist
-          A = mom[(long long)((n * (n + 2) + am) / 2) * mplane + mp];
-          if constexpr (am > 0) B = mom[(long long)((n * (n + 2) - am) / 2) * mplane + mp];
-        } else {
-          A = 0.0;
-        }
+  zk_maps_tail<NMAX, true>(
+      [&](int n, int am, bool valid, double& A, double& B) {
+        // plane j of (n, m) is the reference index j = (n (n + 2) + m) / 2; an absent slot reads plane 0
+        const long long ja = valid ? (n * (n + 2) + am) / 2 : 0, jb = valid ? (n * (n + 2) - am) / 2 : 0;
+        A = mom[ja * mplane + mp];
+        B = am > 0 ? mom[jb * mplane + mp] : 0.0;
       },
       prm, trig, live, plane, pix, rot_out, abs_out, mirror_out);
 }
@@ -367,6 +390,8 @@ int ZK_GROUP_FN(zk_maps_dispatch)(zk_plan* p, const void* in, int dtype, int64_t
 int zk_maps_planes_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                       const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
                       hipStream_t s) {
+  // (bands of <= 1 GiB of moments: smaller bands mean more launches of five under-filled kernels each -- 2048^2 at (48, 20):
+  //  28.8 ms with 1-GiB bands, 45 ms at 256 MiB, 187 ms at 32 MiB)
   int64_t band = (int64_t)((size_t)1 << 30) / ((int64_t)p->n_poly * W * (int64_t)sizeof(double));
   band = band < 4 ? 4 : (band > n_rows ? n_rows : band);
   const size_t need = (size_t)p->n_poly * band * W * sizeof(double);
