@@ -381,6 +381,11 @@ extern "C" int zk_allgather_rows(zk_comm* c, double* full, int64_t n_planes, int
   int64_t my_lo, my_hi;
   window_of(c->rank, H, rpr, row_off, n_rows, &my_lo, &my_hi);
   for (int64_t j = 0; j < n_planes && r == ncclSuccess; ++j) {
+    if (j > 0 && j % 16 == 0) {  // at most 16 planes (16 sends + 16 receives per peer) per group launch
+      r = g_rccl.GroupEnd();
+      if (r == ncclSuccess) r = g_rccl.GroupStart();
+      if (r != ncclSuccess) return rccl_fail(r, "grouped exchange (plane batch)");
+    }
     double* pl = full + j * plane;
     if (algo == 3) {
       for (int owner = 0; owner < c->world && r == ncclSuccess; ++owner) {
