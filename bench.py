@@ -17,8 +17,8 @@ beside it (``kernel_only_patches_per_s``, ``allgather``).
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline       -- the batch kernel: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak
   cpu_baseline   -- the oracle's restatement of the reference CPU path (same NumPy call) on this host
-  north_star_4096, config2_batch, config2_dense, dense_frame, symmetry_pipeline -- the other single-GPU
-                    BASELINE configs, each with its own roofline object (N = 1)
+  north_star_4096, config2_batch, config2_dense, config3_per_gpu, dense_frame, symmetry_pipeline -- the other
+                    BASELINE configs as far as one GPU carries them, each with its own roofline object (N = 1)
   host_api       -- NumPy in / NumPy out through ZPs.transform (PCIe-inclusive; never `value`)
   multi_frame, sharded_maps -- configs[3] / configs[4] on N > 1 ranks
 """
@@ -480,6 +480,23 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
         plan.set_path(_native.PATH_AUTO)
         result["dense_frame"] = dense
         del out_f
+        torch.cuda.empty_cache()
+
+    # ---- configs[3], one GPU's share: 8 frames of 2048^2, dense moments of each into (8, N_poly, H, W) ----------------
+    if not args.no_multi_frame:
+        per_rank = 8
+        frames = torch.stack([torch.from_numpy(honeycomb_frame(H, seed=1000 + i)) for i in range(per_rank)]).to(dev)
+        full = torch.empty((per_rank, n_poly, H, H), dtype=torch.float64, device=dev)
+        ms, launches = _profiled(plan, lambda: [D.frame_moments_device(plan, frames[i], out=full[i]) for i in range(per_rank)], 3)
+        strip = n_max <= 8 and (K + 7) * (K + 63) * 8 <= 80 * 1024 and not os.environ.get("ZK_NO_STRIP")
+        flops = rl.strip_flops_per_unit(z.polynomials[0], n_max) if strip else rl.sep_flops_per_unit(z.polynomials[0], n_max)
+        result["config3_per_gpu"] = {
+            "workload": f"configs[3], one GPU's share of the 64-frame batch: {per_rank} synthetic {H}x{H} frames, dense {K}-px moments "
+                        f"-> ({per_rank}, {n_poly}, {H}, {H}) float64 ({full.numel() * 8 / 1e9:.1f} GB); N > 1 adds the all-gather "
+                        f"('multi_frame')",
+            "kernel_ms_per_pass": ms, "launches_per_pass": launches, "positions_per_s": per_rank * H * H / (ms * 1e-3),
+            "roofline": _fp64_roofline(per_rank * H * H * flops, per_rank * H * H * rl.dense_bytes_per_position(n_max), ms)}
+        del frames, full
         torch.cuda.empty_cache()
 
     # ---- north star's own size: all dense 32-px windows of a 4096^2 frame as one batch ----------------------
