@@ -181,6 +181,24 @@ int zk_frame_maps_dev(zk_plan* plan, const void* image_dev, int dtype, int64_t h
                       const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta, int n_theta,
                       double* rot_dev, double* abs_dev, double* mirror_dev, void* hip_stream);
 
+/*
+ * The same tail on a BATCH of moment vectors -- zmoments.to_complex / rot_maps / mirror_map on rank-2 data (reference
+ * _zmoments.py:300-316, 420-493), e.g. the moments at key points:
+ *   moments (N, n_poly) row-major ->  rot (N, n_folds), abs (N, N_c), mirror (N)   (any output may be NULL)
+ * zk_points_maps = zk_transform_points followed by that tail with the (N, n_poly) matrix never leaving the device
+ * (the reference's notebook flow KeyPoints.extract_patches -> ZPs.transform -> rot_maps).  Full Zernike sets, n_max <= 24.
+ */
+int zk_moment_maps(zk_plan* plan, const double* moments_host, int64_t n_rows, const int32_t* folds, int n_folds,
+                   const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta, int n_theta,
+                   double* rot_host, double* abs_host, double* mirror_host);
+int zk_moment_maps_dev(zk_plan* plan, const double* moments_dev, int64_t n_rows, const int32_t* folds, int n_folds,
+                       const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta, int n_theta,
+                       double* rot_dev, double* abs_dev, double* mirror_dev, void* hip_stream);
+int zk_points_maps(zk_plan* plan, const void* image_host, int dtype, int64_t height, int64_t width,
+                   const int32_t* points_host, int64_t n_points, const int32_t* folds, int n_folds,
+                   const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta, int n_theta,
+                   double* rot_host, double* abs_host, double* mirror_host);
+
 /* As zk_frame_maps_dev with every output plane `plane_stride` doubles apart (see zk_transform_frame_dev_strided);
  * rot_dev / abs_dev / mirror_dev point at the first row of the band inside their full arrays. */
 int zk_frame_maps_dev_strided(zk_plan* plan, const void* image_dev, int dtype, int64_t height, int64_t width,

@@ -320,6 +320,19 @@ extern "C" int zk_frame_maps_dev_strided(zk_plan* p, const void* image, int dtyp
   return rc;
 }
 
+extern "C" int zk_moment_maps_dev(zk_plan* p, const double* moments, int64_t n_rows, const int32_t* folds, int n_folds,
+                                  const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta, int n_theta,
+                                  double* rot, double* ab, double* mirror, void* hip_stream) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  if (n_rows < 0) return zk_fail(ZK_E_BADARG, "negative row count");
+  if (n_rows == 0) return 0;
+  if (!moments) return zk_fail(ZK_E_BADARG, "null device pointer");
+  if (!m_unselect || n_unselect <= 0) return zk_fail(ZK_E_BADARG, "m=0 must be included in m_unselect.");
+  ZK_ON_PLAN_DEVICE(p);
+  return zk_launch_maps_rows(p, moments, n_rows, folds, n_folds, m_unselect, n_unselect, p_norm, theta, n_theta, rot, ab, mirror,
+                             (hipStream_t)hip_stream);
+}
+
 // ------------------------------------------------------------------------------------
 // moments at points
 // ------------------------------------------------------------------------------------

@@ -427,3 +427,133 @@ extern "C" int zk_transform_points(zk_plan* p, const void* image_host, int dtype
         return 0;
       });
 }
+
+// ------------------------------------------------------------------------------------------------------
+// symmetry maps of a batch of moment vectors (rank-2 tail), and of the windows at key points (moments + tail fused:
+// the (N, n_poly) matrix stays on the device)
+// ------------------------------------------------------------------------------------------------------
+namespace {
+
+struct rows_out {
+  double *rot, *ab, *mir;     // host destinations (may be null)
+  int64_t pl_rot, pl_abs, pl_mir;
+};
+
+// D2H of one chunk of the three row-major outputs, packed on the device as [rot | abs | mirror]
+int rows_to_host(const rows_out& o, const double* d, int64_t first, int64_t n, hipStream_t s) {
+  if (o.rot) ZK_HIP(hipMemcpyAsync(o.rot + first * o.pl_rot, d, (size_t)n * o.pl_rot * 8, hipMemcpyDeviceToHost, s));
+  if (o.ab) ZK_HIP(hipMemcpyAsync(o.ab + first * o.pl_abs, d + n * o.pl_rot, (size_t)n * o.pl_abs * 8, hipMemcpyDeviceToHost, s));
+  if (o.mir) ZK_HIP(hipMemcpyAsync(o.mir + first, d + n * (o.pl_rot + o.pl_abs), (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int zk_moment_maps(zk_plan* p, const double* moments_host, int64_t n_rows, const int32_t* folds, int n_folds,
+                              const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta, int n_theta,
+                              double* rot_host, double* abs_host, double* mirror_host) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  if (n_rows < 0) return zk_fail(ZK_E_BADARG, "negative row count");
+  if (n_rows == 0) return 0;
+  if (!moments_host) return zk_fail(ZK_E_BADARG, "null host pointer");
+  ZK_ON_PLAN_DEVICE(p);
+  zk_host_ring* r;
+  int rc;
+  if ((rc = ring_get(p, &r))) return rc;
+  const int64_t nc = zk_complex_count(zk_full_set_nmax(p));
+  const rows_out o = {rot_host, abs_host, mirror_host, rot_host ? n_folds : 0, abs_host ? nc : 0, mirror_host ? 1 : 0};
+  const size_t in_unit = (size_t)p->n_poly * 8, out_unit = (size_t)(o.pl_rot + o.pl_abs + o.pl_mir + 1) * 8;
+  int64_t chunk = (int64_t)(chunk_bytes(p) / (in_unit + out_unit)) & ~(int64_t)255;
+  if (chunk < 256) chunk = 256;
+  if (chunk > n_rows) chunk = n_rows;
+  const int n_chunks = (int)((n_rows + chunk - 1) / chunk);
+  auto count = [&](int c) { return n_rows - c * chunk < chunk ? n_rows - c * chunk : chunk; };
+  return run_chunks(
+      p, r, n_chunks,
+      [&](int c, int slot) -> int {
+        int e = slot_acquire(r, slot);
+        if (!e) e = zk_ensure(&r->d_in[slot], &r->in_cap[slot], (size_t)chunk * in_unit);
+        if (!e) e = zk_ensure(&r->d_out[slot], &r->out_cap[slot], (size_t)chunk * out_unit);
+        if (e) return e;
+        if (c >= ZK_RING_SLOTS) ZK_HIP(hipStreamWaitEvent(r->s_in, r->ev_k[slot], 0));
+        ZK_HIP(hipMemcpyAsync(r->d_in[slot], moments_host + (size_t)c * chunk * p->n_poly, (size_t)count(c) * in_unit,
+                              hipMemcpyHostToDevice, r->s_in));
+        ZK_HIP(hipEventRecord(r->ev_in[slot], r->s_in));
+        ZK_HIP(hipStreamWaitEvent(p->stream, r->ev_in[slot], 0));
+        double* d = (double*)r->d_out[slot];
+        const int64_t n = count(c);
+        e = zk_moment_maps_dev(p, (const double*)r->d_in[slot], n, folds, n_folds, m_unselect, n_unselect, p_norm, theta, n_theta,
+                               o.rot ? d : nullptr, o.ab ? d + n * o.pl_rot : nullptr,
+                               o.mir ? d + n * (o.pl_rot + o.pl_abs) : nullptr, p->stream);
+        if (e) return e;
+        ZK_HIP(hipEventRecord(r->ev_k[slot], p->stream));
+        return 0;
+      },
+      [&](int c, int slot) -> int {
+        ZK_HIP(hipStreamWaitEvent(r->s_out, r->ev_k[slot], 0));
+        const int e = rows_to_host(o, (const double*)r->d_out[slot], (int64_t)c * chunk, count(c), r->s_out);
+        if (e) return e;
+        ZK_HIP(hipEventRecord(r->ev_out[slot], r->s_out));
+        r->out_busy[slot] = true;
+        return 0;
+      });
+}
+
+extern "C" int zk_points_maps(zk_plan* p, const void* image_host, int dtype, int64_t H, int64_t W, const int32_t* points_host,
+                              int64_t n_points, const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect,
+                              int p_norm, const double* theta, int n_theta, double* rot_host, double* abs_host,
+                              double* mirror_host) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  int rc = check_dtype(dtype);
+  if (rc) return rc;
+  if (H <= 0 || W <= 0) return zk_fail(ZK_E_BADARG, "bad frame shape");
+  if (n_points < 0) return zk_fail(ZK_E_BADARG, "negative point count");
+  if (n_points == 0) return 0;
+  if (!image_host || !points_host) return zk_fail(ZK_E_BADARG, "null host pointer");
+  ZK_ON_PLAN_DEVICE(p);
+  zk_host_ring* r;
+  if ((rc = ring_get(p, &r))) return rc;
+  const int kdt = kernel_dtype(dtype);
+  const size_t img_bytes = (size_t)H * W * elem_size(kdt);
+  const size_t img_pad = (img_bytes + 255) & ~(size_t)255;
+  const size_t pts_bytes = (size_t)n_points * 2 * sizeof(int32_t);
+  if ((rc = frame_up(p, r, image_host, dtype, (long long)H * W, img_bytes, img_pad - img_bytes + pts_bytes))) return ring_drain(p, r, rc);
+  int32_t* d_pts = (int32_t*)((char*)r->d_frame + img_pad);
+  {
+    const hipError_t e = hipMemcpyAsync(d_pts, points_host, pts_bytes, hipMemcpyHostToDevice, p->stream);
+    if (e != hipSuccess) return ring_drain(p, r, zk_hip_fail(e, "hipMemcpyAsync(points)"));
+  }
+  const int64_t nc = zk_complex_count(zk_full_set_nmax(p));
+  const rows_out o = {rot_host, abs_host, mirror_host, rot_host ? n_folds : 0, abs_host ? nc : 0, mirror_host ? 1 : 0};
+  const size_t mom_unit = (size_t)p->n_poly * 8, out_unit = (size_t)(o.pl_rot + o.pl_abs + o.pl_mir + 1) * 8;
+  int64_t chunk = (int64_t)(chunk_bytes(p) / (mom_unit + out_unit)) & ~(int64_t)255;
+  if (chunk < 256) chunk = 256;
+  if (chunk > n_points) chunk = n_points;
+  const int n_chunks = (int)((n_points + chunk - 1) / chunk);
+  auto count = [&](int c) { return n_points - c * chunk < chunk ? n_points - c * chunk : chunk; };
+  return run_chunks(
+      p, r, n_chunks,
+      [&](int c, int slot) -> int {
+        int e = slot_acquire(r, slot);
+        if (!e) e = zk_ensure(&r->d_in[slot], &r->in_cap[slot], (size_t)chunk * mom_unit);  // the chunk's moments, device only
+        if (!e) e = zk_ensure(&r->d_out[slot], &r->out_cap[slot], (size_t)chunk * out_unit);
+        if (e) return e;
+        const int64_t n = count(c);
+        double* mom = (double*)r->d_in[slot];
+        double* d = (double*)r->d_out[slot];
+        if ((e = zk_transform_points_dev(p, r->d_frame, kdt, H, W, d_pts + 2 * c * chunk, n, mom, p->stream))) return e;
+        e = zk_moment_maps_dev(p, mom, n, folds, n_folds, m_unselect, n_unselect, p_norm, theta, n_theta, o.rot ? d : nullptr,
+                               o.ab ? d + n * o.pl_rot : nullptr, o.mir ? d + n * (o.pl_rot + o.pl_abs) : nullptr, p->stream);
+        if (e) return e;
+        ZK_HIP(hipEventRecord(r->ev_k[slot], p->stream));
+        return 0;
+      },
+      [&](int c, int slot) -> int {
+        ZK_HIP(hipStreamWaitEvent(r->s_out, r->ev_k[slot], 0));
+        const int e = rows_to_host(o, (const double*)r->d_out[slot], (int64_t)c * chunk, count(c), r->s_out);
+        if (e) return e;
+        ZK_HIP(hipEventRecord(r->ev_out[slot], r->s_out));
+        r->out_busy[slot] = true;
+        return 0;
+      });
+}

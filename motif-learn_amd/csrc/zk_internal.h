@@ -169,5 +169,8 @@ int zk_launch_sep_stream(zk_plan* p, const void* in, int dtype, int64_t n_patche
 int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                        const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
                        const double* theta, int n_theta, double* rot, double* ab, double* mirror, hipStream_t s);
+int zk_launch_maps_rows(zk_plan* p, const double* mom, int64_t n_rows, const int32_t* folds, int n_folds, const int32_t* m_unselect,
+                        int n_unselect, int p_norm, const double* theta, int n_theta, double* rot, double* ab, double* mirror,
+                        hipStream_t s);  // zk_sep_maps.hip: the symmetry-map tail on an (N, n_poly) matrix of moments
 int zk_launch_sep_points(zk_plan* p, const void* img, int dtype, int64_t H, int64_t W, const int32_t* pts,
                          int64_t n_points, double* out, hipStream_t s);

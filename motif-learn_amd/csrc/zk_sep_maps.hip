@@ -64,8 +64,13 @@ __device__ __forceinline__ void zk_for_each_int(F&& f, std::integer_sequence<int
 template <int NMAX, bool BY_ORDER = false, typename GET>
 __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& prm, const double* __restrict__ trig,
                                              bool live, long long plane, long long pix, double* __restrict__ rot_out,
-                                             double* __restrict__ abs_out, double* __restrict__ mirror_out) {
+                                             double* __restrict__ abs_out, double* __restrict__ mirror_out,
+                                             long long pix_rot = -1, long long pix_mir = -1) {
   using Z = zk_set<NMAX>;
+  // (plane, pix) address the |Z| output; the two others default to the same pixel offset (planes layout) and differ in
+  // the rows layout, where a pixel's outputs are rows of (N, n_folds), (N, N_c) and (N)
+  if (pix_rot < 0) pix_rot = pix;
+  if (pix_mir < 0) pix_mir = pix;
   // per-|m| sums over n of the complex moments A + iB:  E = A^2 + B^2,  C = A^2 - B^2,  S = 2AB
   double Em[NMAX + 1], Cm[NMAX + 1], Sm[NMAX + 1];
 #pragma unroll
@@ -139,7 +144,7 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
       double r = 0.0;
 #pragma unroll
       for (int m = 0; m <= NMAX; ++m) r = __builtin_fma(wtab[f * ZK_SEP_ROW + m], Em[m], r);
-      if (live) rot_out[f * plane + pix] = r * inv;
+      if (live) rot_out[f * plane + pix_rot] = r * inv;
     }
   }
   if (mirror_out != nullptr) {
@@ -247,7 +252,7 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
         take(sc);
       }
     }
-    if (live) mirror_out[pix] = best * inv;
+    if (live) mirror_out[pix_mir] = best * inv;
   }
 }
 
@@ -333,6 +338,37 @@ __global__ __launch_bounds__(256) void zk_maps_planes_kernel(const double* __res
       prm, trig, live, plane, pix, rot_out, abs_out, mirror_out);
 }
 
+// Rows form: the tail of a BATCH of moment vectors -- zmoments.to_complex / rot_maps / mirror_map on rank-2 data
+// (reference _zmoments.py:300-316, 420-493; e.g. the moments at key points), one lane per row of the (N, n_poly)
+// row-major matrix, outputs as rows of (N, n_folds), (N, N_c) and (N).
+template <int NMAX>
+__global__ __launch_bounds__(256) void zk_maps_rows_kernel(const double* __restrict__ mom, const double* __restrict__ trig,
+                                                           double* __restrict__ rot_out, double* __restrict__ abs_out,
+                                                           double* __restrict__ mirror_out, zk_maps_params prm, long long n_rows,
+                                                           int n_poly, int n_complex) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = t < n_rows;
+  const double* __restrict__ row = mom + (live ? t : 0) * n_poly;
+  zk_maps_tail<NMAX, true>(
+      [&](int n, int am, bool valid, double& A, double& B) {
+        const int ja = valid ? (n * (n + 2) + am) / 2 : 0, jb = valid ? (n * (n + 2) - am) / 2 : 0;
+        A = row[ja];
+        B = am > 0 ? row[jb] : 0.0;
+      },
+      prm, trig, live, 1, t * n_complex, rot_out, abs_out, mirror_out, t * prm.n_folds, t);
+}
+
+template <int NMAX>
+int launch_rows_one(zk_plan* p, const double* mom, int64_t n_rows, const zk_maps_params& prm, const double* d_trig, double* rot,
+                    double* ab, double* mirror, hipStream_t s) {
+  int rc = zk_prof_begin(p, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(zk_maps_rows_kernel<NMAX>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, mom, d_trig, rot, ab, mirror,
+                     prm, (long long)n_rows, p->n_poly, zk_complex_count(prm.plan_nmax));
+  ZK_HIP(hipGetLastError());
+  return zk_prof_end(p, s);
+}
+
 template <int NMAX, typename T>
 int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
@@ -382,6 +418,28 @@ int ZK_GROUP_FN(zk_maps_dispatch)(zk_plan* p, const void* in, int dtype, int64_t
                                   double* mirror, hipStream_t s) {
   if (dtype == ZK_F32) return launch_t<float>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
   return launch_t<double>(p, in, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+}
+
+int ZK_GROUP_FN(zk_maps_rows_dispatch)(zk_plan* p, const double* mom, int64_t n_rows, const zk_maps_params& prm, const double* d_trig,
+                                       double* rot, double* ab, double* mirror, hipStream_t s) {
+  switch (p->sep->kernel_nmax) {
+#if ZK_NMAX_GROUP == 0
+    case 4: return launch_rows_one<4>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 6: return launch_rows_one<6>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 8: return launch_rows_one<8>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 10: return launch_rows_one<10>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 12: return launch_rows_one<12>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+#endif
+#if ZK_NMAX_GROUP == 1
+    case 14: return launch_rows_one<14>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 16: return launch_rows_one<16>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+#endif
+#if ZK_NMAX_GROUP == 2
+    case 20: return launch_rows_one<20>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 24: return launch_rows_one<24>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+#endif
+  }
+  return zk_fail(ZK_E_BADARG, "no symmetry-map rows kernel for this n_max");
 }
 
 #if ZK_NMAX_GROUP == 2
@@ -437,11 +495,15 @@ bool zk_sep_maps_available(const zk_plan* p, int dtype) {
   return zk_sep_frame_available(p, dtype);  // n_max <= 16: fused in one kernel; 17-20: dense passes + planes kernel
 }
 
-int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
-                       const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
-                       const double* theta, int n_theta, double* rot, double* ab, double* mirror, hipStream_t s) {
-  if (!zk_sep_maps_available(p, dtype))
-    return zk_fail(ZK_E_BADARG, "plan has no symmetry-map kernels (needs the separable tables: full Zernike set, n_max <= 24)");
+int zk_maps_rows_dispatch_g1(zk_plan* p, const double* mom, int64_t n_rows, const zk_maps_params& prm, const double* d_trig,
+                             double* rot, double* ab, double* mirror, hipStream_t s);
+int zk_maps_rows_dispatch_g2(zk_plan* p, const double* mom, int64_t n_rows, const zk_maps_params& prm, const double* d_trig,
+                             double* rot, double* ab, double* mirror, hipStream_t s);
+
+// options -> kernel parameters + the device table of fold weights / angles (cached per option set)
+static int maps_setup(zk_plan* p, const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
+                      const double* theta, int n_theta, double* rot, double* mirror, zk_maps_params* prm_out,
+                      const double** d_trig_out) {
   if (n_folds < 0 || n_folds > ZK_MAX_FOLDS) return zk_fail(ZK_E_BADARG, "at most 8 folds per call");
   if (p_norm != 0 && p_norm != 2) return zk_fail(ZK_E_BADARG, "p must be 2 or 0 (None)");
   if (rot && (!folds || n_folds == 0)) return zk_fail(ZK_E_BADARG, "rot output requested without folds");
@@ -527,8 +589,39 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
     d_trig = e.dev;
     t->trig_cache.insert(t->trig_cache.begin(), std::move(e));
   }
+  *prm_out = prm;
+  *d_trig_out = d_trig;
+  return 0;
+}
+
+int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                       const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
+                       const double* theta, int n_theta, double* rot, double* ab, double* mirror, hipStream_t s) {
+  if (!zk_sep_maps_available(p, dtype))
+    return zk_fail(ZK_E_BADARG, "plan has no symmetry-map kernels (needs the separable tables: full Zernike set, n_max <= 24)");
+  zk_maps_params prm;
+  const double* d_trig = nullptr;
+  int rc = maps_setup(p, folds, n_folds, m_unselect, n_unselect, p_norm, theta, n_theta, rot, mirror, &prm, &d_trig);
+  if (rc) return rc;
+  const int knm = p->sep->kernel_nmax;
   if (knm > 16) return zk_maps_planes_g2(p, in, dtype, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
   if (knm > 12) return zk_maps_dispatch_g1(p, in, dtype, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
   return zk_maps_dispatch(p, in, dtype, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
+}
+
+// the same tail on a batch of moment vectors already in device memory: (N, n_poly) -> (N, n_folds), (N, N_c), (N)
+int zk_launch_maps_rows(zk_plan* p, const double* mom, int64_t n_rows, const int32_t* folds, int n_folds, const int32_t* m_unselect,
+                        int n_unselect, int p_norm, const double* theta, int n_theta, double* rot, double* ab, double* mirror,
+                        hipStream_t s) {
+  if (!p->sep || zk_full_set_nmax(p) < 0)
+    return zk_fail(ZK_E_BADARG, "plan has no symmetry-map kernels (needs the separable tables: full Zernike set, n_max <= 24)");
+  zk_maps_params prm;
+  const double* d_trig = nullptr;
+  int rc = maps_setup(p, folds, n_folds, m_unselect, n_unselect, p_norm, theta, n_theta, rot, mirror, &prm, &d_trig);
+  if (rc) return rc;
+  const int knm = p->sep->kernel_nmax;
+  if (knm > 16) return zk_maps_rows_dispatch_g2(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+  if (knm > 12) return zk_maps_rows_dispatch_g1(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+  return zk_maps_rows_dispatch(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
 }
 #endif

@@ -51,6 +51,12 @@ SYMBOLS = {
     "zk_frame_maps_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, POINTER(c_int32),
                                   c_int, POINTER(c_int32), c_int, c_int, POINTER(c_double), c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
+    "zk_moment_maps": (c_int, [c_void_p, POINTER(c_double), c_int64, POINTER(c_int32), c_int, POINTER(c_int32), c_int, c_int,
+                               POINTER(c_double), c_int, c_void_p, c_void_p, c_void_p]),
+    "zk_moment_maps_dev": (c_int, [c_void_p, c_void_p, c_int64, POINTER(c_int32), c_int, POINTER(c_int32), c_int, c_int,
+                                   POINTER(c_double), c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "zk_points_maps": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, POINTER(c_int32), c_int64, POINTER(c_int32), c_int,
+                               POINTER(c_int32), c_int, c_int, POINTER(c_double), c_int, c_void_p, c_void_p, c_void_p]),
     "zk_transform_frame_dev_strided": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
                                                c_void_p, c_int64, c_void_p]),
     "zk_frame_maps_dev_strided": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
@@ -322,6 +328,37 @@ class Plan:
             th.ctypes.data_as(POINTER(c_double)) if th is not None else None, 0 if th is None else len(th),
             ptr(rot), ptr(ab), ptr(mir)), "zk_frame_maps")
         return rot, ab, mir
+
+    def _rows_maps(self, n_rows, n_complex, folds, m_unselect, p, theta, want_abs, call):
+        folds32 = np.ascontiguousarray(folds if folds is not None else [], dtype=np.int32)
+        unsel32 = np.ascontiguousarray(m_unselect, dtype=np.int32)
+        rot = pinned.empty((n_rows, len(folds32))) if len(folds32) else None
+        ab = pinned.empty((n_rows, n_complex)) if want_abs else None
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        mir = pinned.empty((n_rows,)) if th is not None else None
+        ptr = lambda a: a.ctypes.data_as(c_void_p) if a is not None else None
+        call(folds32.ctypes.data_as(POINTER(c_int32)), len(folds32),
+             unsel32.ctypes.data_as(POINTER(c_int32)), len(unsel32), 2 if p == 2 else 0,
+             th.ctypes.data_as(POINTER(c_double)) if th is not None else None, 0 if th is None else len(th),
+             ptr(rot), ptr(ab), ptr(mir))
+        return rot, ab, mir
+
+    def moment_maps(self, moments, n_complex, folds=None, m_unselect=(0, 1), p=2, theta=None, want_abs=True):
+        """(N, n_poly) host moments -> (rot (N, n_folds), |Z^c| (N, N_c), mirror (N)); None when not requested."""
+        mom = np.ascontiguousarray(moments, dtype=np.float64)
+        return self._rows_maps(mom.shape[0], n_complex, folds, m_unselect, p, theta, want_abs,
+                               lambda *tail: check(self._lib.zk_moment_maps(
+                                   self._h, mom.ctypes.data_as(POINTER(c_double)), mom.shape[0], *tail), "zk_moment_maps"))
+
+    def points_maps(self, image, points, n_complex, folds=None, m_unselect=(0, 1), p=2, theta=None, want_abs=True):
+        """Windows at integer (x, y) points of a host frame -> the same three outputs; the moments stay on the device."""
+        code = dtype_code(image.dtype)
+        h, w = image.shape
+        pts = np.ascontiguousarray(points, dtype=np.int32).reshape(-1, 2)
+        return self._rows_maps(pts.shape[0], n_complex, folds, m_unselect, p, theta, want_abs,
+                               lambda *tail: check(self._lib.zk_points_maps(
+                                   self._h, image.ctypes.data_as(c_void_p), code, h, w,
+                                   pts.ctypes.data_as(POINTER(c_int32)), pts.shape[0], *tail), "zk_points_maps"))
 
     def frame_maps_dev(self, image_ptr, code, height, width, row0, n_rows, folds, m_unselect, p, theta,
                        rot_ptr, abs_ptr, mirror_ptr, stream=0, plane_stride=None):

@@ -307,6 +307,69 @@ class ZPs(BaseEstimator, TransformerMixin):
         out["valid_mask"] = self._valid_mask(height, width)   # same convention as zmoments.valid_mask
         return out
 
+    def _rows_options(self, n_folds, p, m_unselect, theta, mirror):
+        if m_unselect is None:
+            m_unselect = (0, 1)
+        if 0 not in m_unselect:
+            raise ValueError("m=0 must be included in m_unselect.")
+        folds = [] if n_folds is None else list(np.atleast_1d(n_folds).ravel())
+        if mirror and theta is None:
+            theta = np.linspace(0, 2 * np.pi, 360, endpoint=False)
+        complex_n = np.array([n for n in range(self.n_max + 1) for _ in range(n % 2, n + 1, 2)])
+        complex_m = np.array([m for n in range(self.n_max + 1) for m in range(n % 2, n + 1, 2)])
+        fused = (self._device_plan().supports(_native.OP_MAPS, _native.ZK_F64) and p in (2, None) and len(folds) <= 8
+                 and all(int(f) == f and f > 0 for f in folds))
+        return folds, m_unselect, theta if mirror else None, complex_n, complex_m, fused
+
+    @staticmethod
+    def _rows_result(rot, ab, mir, complex_n, complex_m):
+        out = {}
+        if rot is not None:
+            out["rot_maps"] = rot
+        if ab is not None:
+            out["abs"], out["abs_n"], out["abs_m"] = ab, complex_n, complex_m
+        if mir is not None:
+            out["mirror_map"] = mir
+        return out
+
+    def symmetry_of(self, moments, n_folds=(2, 3, 4, 6), p=2, m_unselect=(0, 1), theta=None, abs_moments=True, mirror=True):
+        """Symmetry scores of a BATCH of moment vectors on the GPU (extension): ``moments`` is a rank-2 ``zmoments`` of this
+        set or an ``(N, n_poly)`` array.  Equivalent to ``zm.rot_maps(n_folds, p, m_unselect)`` -> ``(N, len(n_folds))``,
+        ``np.abs(zm.to_complex().data)`` -> ``(N, N_c)`` and ``zm.mirror_map(theta, p, m_unselect)`` -> ``(N,)``
+        (reference ``_zmoments.py:300-316, 420-493`` on rank-2 data), one lane per row."""
+        data = np.asarray(moments.data if isinstance(moments, zmoments) else moments, dtype=np.float64)
+        if data.ndim != 2 or data.shape[1] != len(self.n):
+            raise ValueError(f"symmetry_of needs an (N, {len(self.n)}) matrix of real Zernike moments.")
+        folds, m_unselect, theta, cn, cm, fused = self._rows_options(n_folds, p, m_unselect, theta, mirror)
+        if data.shape[0] == 0 or not fused:
+            zm = zmoments(data, self.n, self.m, patch_size=self.size)
+            return self._rows_result(zm.rot_maps(folds, p=p, m_unselect=m_unselect) if folds else None,
+                                     np.abs(zm.to_complex().data) if abs_moments else None,
+                                     zm.mirror_map(theta=theta, p=p, m_unselect=m_unselect) if mirror else None, cn, cm)
+        with self._lock:
+            rot, ab, mir = self._device_plan().moment_maps(data, len(cn), folds=folds, m_unselect=m_unselect, p=p, theta=theta,
+                                                           want_abs=abs_moments)
+        return self._rows_result(rot, ab, mir, cn, cm)
+
+    def symmetry_at(self, image, points, n_folds=(2, 3, 4, 6), p=2, m_unselect=(0, 1), theta=None, abs_moments=True,
+                    mirror=True):
+        """Symmetry scores of the windows centred on key points (extension) = ``symmetry_of(transform_at(image, points))``
+        -- the reference's notebook flow ``KeyPoints.extract_patches`` -> ``ZPs.transform`` -> ``rot_maps`` -- with neither
+        the patch batch nor the ``(N, n_poly)`` moment matrix leaving the GPU."""
+        image = np.asarray(image)
+        if image.ndim != 2:
+            raise ValueError("symmetry_at needs a 2D image.")
+        pts = np.rint(np.asarray(points, dtype=np.float64)).astype(np.int64).reshape(-1, 2)
+        folds, m_unselect, theta, cn, cm, fused = self._rows_options(n_folds, p, m_unselect, theta, mirror)
+        if pts.shape[0] == 0 or not fused:
+            return self.symmetry_of(self.transform_at(image, pts), n_folds=n_folds, p=p, m_unselect=m_unselect, theta=theta,
+                                    abs_moments=abs_moments, mirror=mirror)
+        operand = self._device_operand(image)
+        with self._lock:
+            rot, ab, mir = self._device_plan().points_maps(operand, pts, len(cn), folds=folds, m_unselect=m_unselect, p=p,
+                                                           theta=theta, want_abs=abs_moments)
+        return self._rows_result(rot, ab, mir, cn, cm)
+
     def _valid_mask(self, height, width):
         head = (self.size - 1) // 2
         tail = self.size - 1 - head

@@ -159,6 +159,92 @@ def test_moments_at_key_points(native, zo):
     assert z.transform_at(frame, np.empty((0, 2))).data.shape == (0, 45)
 
 
+def test_symmetry_of_moment_rows(native, golden, zo):
+    """zk_moment_maps / zk_points_maps: the zmoments tail on rank-2 data (reference _zmoments.py:300-316, 420-493) --
+    golden vectors of the reference (its rot_maps / mirror_map / to_complex on the moments of four blob patches), then the
+    oracle's tail on oracle moments for every n_max group, every output subset, ragged counts and several host chunks."""
+    z = _zps(8, 32)
+    mom = golden["Z_blobs_8_32"]
+    got = z.symmetry_of(mom)
+    rel_close(got["rot_maps"], golden["pp2_rot_maps"], rtol=1e-8)
+    rel_close(got["mirror_map"], golden["pp2_mirror"], rtol=1e-8)
+    rel_close(got["abs"], np.abs(golden["pp2_complex"]), rtol=1e-8)
+    np.testing.assert_array_equal(got["abs_n"], golden["pp2_complex_n"])
+    np.testing.assert_array_equal(got["abs_m"], golden["pp2_complex_m"])
+    rel_close(z.symmetry_of(mom, n_folds=[3, 6], p=None, mirror=False)["rot_maps"], golden["pp2_rot_maps_pnone"], rtol=1e-8)
+    rel_close(z.symmetry_of(mom, n_folds=[3], m_unselect=(0, 1, 2), mirror=False)["rot_maps"], golden["pp2_rot_maps_unsel012"],
+              rtol=1e-8)
+    # the whole flow from the patches, moments never on the host: frame with the four blobs pasted in, points at their centres
+    frame = np.zeros((80, 200), dtype=np.float32)
+    pts = []
+    for i, blob in enumerate(golden["blobs_32"]):
+        frame[20:52, 10 + 45 * i:42 + 45 * i] = blob
+        pts.append((10 + 45 * i + 16, 20 + 16))
+    at = z.symmetry_at(frame, pts)
+    rel_close(at["rot_maps"], golden["pp2_rot_maps"], rtol=1e-8)
+    rel_close(at["mirror_map"], golden["pp2_mirror"], rtol=1e-8)
+    rel_close(at["abs"], np.abs(golden["pp2_complex"]), rtol=1e-8)
+
+    rng = np.random.default_rng(314)
+    for n_max, size, n_rows in [(4, 16, 1), (6, 12, 257), (8, 32, 3000), (10, 32, 700), (12, 40, 513), (14, 32, 300),
+                                (16, 36, 255), (20, 44, 130), (23, 48, 70)]:
+        zz = _zps(n_max, size)
+        mom = rng.standard_normal((n_rows, len(zz.n))) * np.exp(rng.uniform(-3, 3, (n_rows, 1)))
+        for kw in (dict(), dict(n_folds=[2, 5], m_unselect=(0, 2), p=None, theta=np.linspace(0, 2 * np.pi, 48, endpoint=False)),
+                   dict(n_folds=[1, 2, 3, 4, 5, 6, 7, 8], theta=np.linspace(0, np.pi, 37))):
+            got = zz.symmetry_of(mom, **kw)
+            folds, unsel, pp = kw.get("n_folds", [2, 3, 4, 6]), kw.get("m_unselect", (0, 1)), kw.get("p", 2)
+            rel_close(got["rot_maps"], zo.rot_maps(mom, zz.n, zz.m, list(folds), p=pp, m_unselect=unsel), rtol=1e-9)
+            rel_close(got["abs"], np.abs(zo.to_complex(mom, zz.n, zz.m)[0]), rtol=1e-12)
+            rel_close(got["mirror_map"], zo.mirror_map(mom, zz.n, zz.m, theta=kw.get("theta"), p=pp, m_unselect=unsel), rtol=1e-9)
+        only = zz.symmetry_of(mom, n_folds=None, abs_moments=False)
+        assert set(only) == {"mirror_map"} and only["mirror_map"].shape == (n_rows,)
+        only = zz.symmetry_of(mom, mirror=False, abs_moments=False, n_folds=[4])
+        assert set(only) == {"rot_maps"} and only["rot_maps"].shape == (n_rows, 1)
+    # several host chunks == one chunk, and a zmoments operand; a NaN row stays in its row
+    zz = _zps(8, 32)
+    mom = rng.standard_normal((5000, 45))
+    mom[17, 3] = np.nan
+    one = zz.symmetry_of(mom)
+    plan = zz._device_plan()
+    plan.set_host_chunk(1 << 18)
+    try:
+        many = zz.symmetry_of(zz.transform(np.zeros((1, 32, 32), dtype=np.float32))._like(mom))
+    finally:
+        plan.set_host_chunk(0)
+    for key in ("rot_maps", "abs", "mirror_map"):
+        np.testing.assert_array_equal(one[key], many[key])
+    assert np.isnan(one["rot_maps"][17]).all() and np.isnan(one["mirror_map"][17]) and np.isfinite(np.delete(one["rot_maps"], 17, 0)).all()
+    assert zz.symmetry_of(np.empty((0, 45)))["rot_maps"].shape == (0, 4)
+    with pytest.raises(ValueError):
+        zz.symmetry_of(mom[:, :44])
+    with pytest.raises(ValueError):
+        zz.symmetry_of(mom, m_unselect=(1,))
+
+    # key points end to end against the oracle (reference slicing -> oracle moments -> oracle tail), incl. plans that cut
+    # the windows on the device (n_max > 16) and a chunked run
+    for n_max, size, dtype in [(8, 32, np.float32), (12, 40, np.float64), (16, 32, np.float32), (18, 40, np.float32)]:
+        zz = _zps(n_max, size)
+        frame = (rng.random((150, 210)) + 0.1).astype(dtype)
+        margin = size // 2 + 2
+        ipts = np.column_stack([rng.integers(margin, 210 - margin, 1200), rng.integers(margin, 150 - margin, 1200)])
+        s1, s2 = size // 2, size - size // 2
+        patches = np.array([frame[y - s1:y + s2, x - s1:x + s2] for x, y in ipts])
+        o_mom = zo.moments_patches(patches, zz.polynomials)
+        floor = 1e-7 if n_max > 16 else 1e-9 if n_max > 12 else 1e-10
+        plan = zz._device_plan()
+        for chunk in (0, 1 << 18):
+            plan.set_host_chunk(chunk)
+            try:
+                got = zz.symmetry_at(frame, ipts)
+            finally:
+                plan.set_host_chunk(0)
+            rel_close(got["rot_maps"], zo.rot_maps(o_mom, zz.n, zz.m, [2, 3, 4, 6], p=2, m_unselect=(0, 1)), atol_scale=floor)
+            rel_close(got["abs"], np.abs(zo.to_complex(o_mom, zz.n, zz.m)[0]), atol_scale=floor)
+            rel_close(got["mirror_map"], zo.mirror_map(o_mom, zz.n, zz.m, theta=None, p=2, m_unselect=(0, 1)), atol_scale=floor)
+    assert zz.symmetry_at(frame, np.empty((0, 2)))["rot_maps"].shape == (0, 4)
+
+
 def test_strided_grid_matches_reference_extractor(native, zo):
     """transform_grid == reference extract_patches(image, size, step) (denoise/_denoise_svd.py:15-49,
     restated here) followed by the batch transform."""
