@@ -331,6 +331,48 @@ int zk_gram_dev(int device, const double* X_dev, int64_t n_rows, int n_features,
 int zk_project_dev(int device, const double* X_dev, int64_t n_rows, int n_features, const double* mean_dev,
                    const double* components_dev, int n_components, double* Y_dev, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Clustering consumers of the moment matrix, csrc/zk_cluster.hip:
+ *   kmeans_lbs(X, n)   reference clustering/_clustering_functions.py:8-22  (sklearn KMeans(n, random_state).fit(X).labels_)
+ *   gmm_lbs(X, n)      reference clustering/_clustering_functions.py:25-33 (sklearn GaussianMixture(n, type).fit(X).predict(X))
+ * zk_rows = a float64 matrix (N, D), D <= 127, resident on one device together with the work buffers of these passes.
+ * Every pass over the matrix is one call here; what happens between passes (random draws, centre updates, D x D Cholesky
+ * factors, convergence tests) is scikit-learn's control flow, restated by the caller (mtflearn_amd/features/consumers.py).
+ * Results do not depend on scheduling: per-workgroup partial sums are reduced in a fixed order.
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct zk_rows zk_rows;
+int zk_rows_create(int device, const double* X_host, int64_t n_rows, int n_features, zk_rows** out); /* uploads a copy */
+int zk_rows_adopt(int device, const double* X_dev, int64_t n_rows, int n_features, zk_rows** out);   /* borrows X_dev */
+int zk_rows_destroy(zk_rows* rows);
+const double* zk_rows_data(const zk_rows* rows);                 /* the device matrix */
+/* Column means and population variances (two passes, as numpy.mean / numpy.var); the means become the centring shift of
+ * the k-means calls (scikit-learn subtracts them before clustering); n_bad_out = rows with a non-finite element. */
+int zk_rows_center(zk_rows* rows, double* mean_out, double* var_out, int64_t* n_bad_out);
+int zk_rows_fetch(zk_rows* rows, const int64_t* idx, int n, int centred, double* rows_out);   /* (n, D) to the host */
+int zk_rows_reset_labels(zk_rows* rows);                         /* labels := -1 (a new k-means run) */
+int zk_rows_labels(zk_rows* rows, int32_t* labels_host);         /* (N) labels of the last k-means / E step */
+const int32_t* zk_rows_labels_dev(const zk_rows* rows);
+/* k-means++ seeding (sklearn _kmeans_plusplus): squared distances of every centred row to t <= 8 candidate rows
+ * (cand (t, D) centred, cand_sq their squared norms), max(0, (-2 x.c + |c|^2) + |x|^2), folded with the closest distance
+ * so far when use_closest; pot_out[c] = their sum over the rows.  zk_kmeans_seed_pick adopts candidate `which` as the
+ * closest-distance row and returns searchsorted(cumsum(closest), vals) clipped to N - 1 (n_vals may be 0). */
+int zk_kmeans_seed_step(zk_rows* rows, const double* cand, const double* cand_sq, int t, int use_closest, double* pot_out);
+int zk_kmeans_seed_pick(zk_rows* rows, int which, const double* vals, int n_vals, int64_t* idx_out);
+/* One Lloyd pass (sklearn lloyd_iter_chunked_dense) with the centred centres (k, D), k <= 256: label = first argmin_c
+ * (|c|^2 - 2 x.c); with `update` sums_out (k, D) = sum of the centred rows per cluster, counts_out (k);
+ * n_changed_out = rows whose label changed. */
+int zk_kmeans_step(zk_rows* rows, const double* centers, int k, int update, double* sums_out, double* counts_out,
+                   int64_t* n_changed_out);
+int zk_kmeans_own_distance(zk_rows* rows, const double* centers, int k, double* dist_host);   /* |x - c[label]|^2, (N) */
+/* Gaussian mixture (sklearn _estimate_log_gaussian_prob / _estimate_log_prob_resp / _estimate_gaussian_parameters):
+ * E step with upper-triangular precision Cholesky factors (k, D, D), means (k, D), log-determinants and log weights (k):
+ * responsibilities (k, N) and labels (first argmax) stay on the device, lse_sum_out = sum_r logsumexp_c; the M step's
+ * sums of one component about `shift`: gram_out (D+1, D+1) = sum_r resp[c][r] [x_r - shift | 1]^T [x_r - shift | 1]. */
+int zk_gmm_estep(zk_rows* rows, const double* prec_chol, const double* means, const double* log_det, const double* log_w, int k,
+                 int want_resp, double* lse_sum_out);
+int zk_gmm_resp_from_labels(zk_rows* rows, int k);               /* one-hot of the current labels */
+int zk_gmm_moments(zk_rows* rows, int component, const double* shift, double* gram_out);
+
 /* Device memory for callers that have no allocator of their own (a NumPy / C user of the *_dev entry points). */
 int zk_device_malloc(int device, int64_t bytes, void** out_dev);
 int zk_device_free(int device, void* dev);

@@ -1,0 +1,885 @@
+// zk_cluster.hip -- clustering consumers of the moment matrix on the device:
+//   kmeans_lbs(X, n)   reference clustering/_clustering_functions.py:8-22  (sklearn KMeans(n, random_state).fit(X).labels_)
+//   gmm_lbs(X, n)      reference clustering/_clustering_functions.py:25-33 (sklearn GaussianMixture(n, type).fit(X).predict(X))
+// The (N, D) float64 matrix stays in HBM (zk_rows); every pass over it is a kernel here, the decisions between passes
+// (random draws, centre updates, D x D Cholesky factors, convergence tests) are scikit-learn's own control flow restated
+// in the Python wrapper (mtflearn_amd/features/consumers.py).
+//
+// Common shape of the row kernels: a workgroup is ONE wave that owns tiles of 64 consecutive rows.  A tile is 64*D
+// contiguous doubles: it is copied with coalesced loads into LDS (row stride S = D | 1 doubles, so that the later
+// lane = row reads are conflict-free), then lane r walks its row while everything that is not a matrix element -- centre
+// coordinates, Cholesky factors, column means -- is wave-uniform and arrives through scalar loads (as in the moment
+// kernels).  Column sums per cluster are built the other way round (lane = column, the row's label wave-uniform) with
+// LDS floating-point adds into a wave-private table.  Per-workgroup partial results are written out and summed by a second
+// kernel in a fixed order: results do not depend on scheduling (bit-identical from run to run on the same device).
+#include "zk_internal.h"
+#include "zk_fold.h"  // ZK_CONST / zk_const
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+struct zk_rows {
+  int device = 0;
+  int n_cu = 256;
+  int64_t N = 0;
+  int D = 0, S = 0;
+  const double* X = nullptr;
+  bool own = false;
+  hipStream_t stream = nullptr;
+  double* d_mean = nullptr;      // [D] the centring shift (column means; zeros until zk_rows_center)
+  double* d_xsq = nullptr;       // [N] squared norms of the centred rows
+  void* d_tab = nullptr;         // wave-uniform operand tables of the current call
+  size_t tab_bytes = 0;
+  void* d_part = nullptr;        // per-workgroup partial results
+  size_t part_bytes = 0;
+  void* d_red = nullptr;         // reduced results
+  size_t red_bytes = 0;
+  void* d_seed[2] = {nullptr, nullptr};  // k-means++: (t, N) candidate distance rows, ping-pong
+  size_t seed_bytes[2] = {0, 0};
+  int seed_cur = 0;              // buffer that holds the current closest-distance row
+  const double* d_closest = nullptr;
+  int seed_t = 0;                // candidates of the last zk_kmeans_seed_step ...
+  int seed_last = -1;            // ... and the buffer their distance rows are in
+  int32_t* d_labels = nullptr;   // [N]
+  void* d_resp = nullptr;        // (k, N) responsibilities
+  size_t resp_bytes = 0;
+  unsigned long long* d_count = nullptr;  // [4] integer counters
+  std::vector<double> h_buf;
+};
+
+namespace {
+
+constexpr int TILE = 64;
+
+__device__ __forceinline__ void tile_load(const double* __restrict__ X, long long total, int D, int S, long long base,
+                                          double* __restrict__ tile, int lane) {
+  int row = lane / D, col = lane - row * D;
+  const int adv_row = TILE / D, adv_col = TILE - adv_row * D;
+#pragma unroll 8
+  for (int q = 0; q < D; ++q) {
+    const long long e = base + (long long)q * TILE + lane;
+    tile[row * S + col] = e < total ? __builtin_nontemporal_load(X + e) : 0.0;
+    row += adv_row;
+    col += adv_col;
+    if (col >= D) {
+      col -= D;
+      ++row;
+    }
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- column statistics: part[block][D] = sum over the block's rows of (x - shift) or (x - shift)^2 ---------------------
+__global__ __launch_bounds__(64) void colsum_kernel(const double* __restrict__ X, long long N, int D, int S,
+                                                    const double* __restrict__ shift, int square, double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* tile = lds;
+  const int lane = threadIdx.x;
+  const long long total = N * D;
+  const int j0 = lane, j1 = lane + 64;
+  const double m0 = shift && j0 < D ? shift[j0] : 0.0, m1 = shift && j1 < D ? shift[j1] : 0.0;
+  double a0 = 0.0, a1 = 0.0;
+  for (long long t = blockIdx.x; t * TILE < N; t += gridDim.x) {
+    __syncthreads();
+    tile_load(X, total, D, S, t * TILE * D, tile, lane);
+    __syncthreads();
+    const int rows = (int)(N - t * TILE < TILE ? N - t * TILE : TILE);
+    for (int r = 0; r < rows; ++r) {
+      if (j0 < D) {
+        const double v = tile[r * S + j0] - m0;
+        a0 += square ? v * v : v;
+      }
+      if (j1 < D) {
+        const double v = tile[r * S + j1] - m1;
+        a1 += square ? v * v : v;
+      }
+    }
+  }
+  if (j0 < D) part[(long long)blockIdx.x * D + j0] = a0;
+  if (j1 < D) part[(long long)blockIdx.x * D + j1] = a1;
+}
+
+// out[i] = sum over blocks (ascending) of part[block][i]
+__global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ part, int n_blocks, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < n_blocks; ++b) s += part[(long long)b * n + i];
+  out[i] = s;
+}
+
+// xsq[r] = sum_j (x_rj - mean_j)^2 (row_norms of the centred matrix); count[0] += rows whose norm is not finite
+__global__ __launch_bounds__(64) void rownorm_kernel(const double* __restrict__ X, long long N, int D, int S,
+                                                     const double* __restrict__ mean, double* __restrict__ xsq,
+                                                     unsigned long long* __restrict__ count) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* tile = lds;
+  const int lane = threadIdx.x;
+  const long long total = N * D;
+  const ZK_CONST double* cm = zk_const(mean);
+  unsigned long long bad = 0;
+  for (long long t = blockIdx.x; t * TILE < N; t += gridDim.x) {
+    __syncthreads();
+    tile_load(X, total, D, S, t * TILE * D, tile, lane);
+    __syncthreads();
+    const double* row = tile + lane * S;
+    double s = 0.0;
+    for (int i = 0; i < D; ++i) {
+      const double v = row[i] - cm[i];
+      s = __builtin_fma(v, v, s);
+    }
+    const long long r = t * TILE + lane;
+    if (r < N) {
+      xsq[r] = s;
+      bad += !(s <= 1.7976931348623157e308);
+    }
+  }
+  const unsigned long long any = __ballot(bad != 0);
+  if (any && bad) atomicAdd(count, bad);
+}
+
+// dots of the centred row with four wave-uniform vectors: Ct is [D][KP] (vector index fastest)
+__device__ __forceinline__ void dots4(const double* __restrict__ row, int D, const ZK_CONST double* cm, const ZK_CONST double* ct,
+                                      int KP, double& d0, double& d1, double& d2, double& d3) {
+  d0 = d1 = d2 = d3 = 0.0;
+  for (int i = 0; i < D; ++i) {
+    const double v = row[i] - cm[i];
+    const ZK_CONST double* c = ct + (long long)i * KP;
+    d0 = __builtin_fma(v, c[0], d0);
+    d1 = __builtin_fma(v, c[1], d1);
+    d2 = __builtin_fma(v, c[2], d2);
+    d3 = __builtin_fma(v, c[3], d3);
+  }
+}
+
+// ---- k-means++ seeding step (sklearn/cluster/_kmeans.py _kmeans_plusplus): squared distances of every row to TP <= 8
+// candidate rows, d = max(0, (-2 x.c + |c|^2) + |x|^2) as sklearn's _euclidean_distances builds them, folded with the
+// closest distance so far; out[c][r]; part[block][c] = potential of candidate c over the block's rows ----------------
+template <int TP>
+__global__ __launch_bounds__(64) void seed_kernel(const double* __restrict__ X, long long N, int D, int S,
+                                                  const double* __restrict__ mean, const double* __restrict__ Ct,
+                                                  const double* __restrict__ cc, int t, const double* __restrict__ xsq,
+                                                  const double* __restrict__ closest, double* __restrict__ out,
+                                                  double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* tile = lds;
+  const int lane = threadIdx.x;
+  const long long total = N * D;
+  const ZK_CONST double* cm = zk_const(mean);
+  const ZK_CONST double* ct = zk_const(Ct);
+  const ZK_CONST double* ccc = zk_const(cc);
+  double pot[TP];
+#pragma unroll
+  for (int c = 0; c < TP; ++c) pot[c] = 0.0;
+  for (long long tl = blockIdx.x; tl * TILE < N; tl += gridDim.x) {
+    __syncthreads();
+    tile_load(X, total, D, S, tl * TILE * D, tile, lane);
+    __syncthreads();
+    const double* row = tile + lane * S;
+    const long long r = tl * TILE + lane;
+    const bool live = r < N;
+    const double xs = live ? xsq[r] : 0.0;
+    const double prev = closest && live ? closest[r] : std::numeric_limits<double>::infinity();
+#pragma unroll
+    for (int c0 = 0; c0 < TP; c0 += 4) {
+      double d[4];
+      dots4(row, D, cm, ct + c0, TP, d[0], d[1], d[2], d[3]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double v = __builtin_fma(-2.0, d[c], ccc[c0 + c]) + xs;
+        v = v > 0.0 ? v : 0.0;
+        v = v < prev ? v : prev;
+        if (live && c0 + c < t) {
+          out[(long long)(c0 + c) * N + r] = v;
+          pot[c0 + c] += v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < TP; ++c) {
+    const double s = wave_sum(pot[c]);
+    if (lane == 0) part[(long long)blockIdx.x * TP + c] = s;
+  }
+}
+
+// sums of consecutive blocks of 1024 elements (for searchsorted(cumsum(a), v))
+__global__ __launch_bounds__(256) void blocksum_kernel(const double* __restrict__ a, long long n, double* __restrict__ bsum) {
+  __shared__ double w[4];
+  const long long base = (long long)blockIdx.x * 1024;
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const long long i = base + q * 256 + threadIdx.x;
+    s += i < n ? a[i] : 0.0;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bsum[blockIdx.x] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+
+// ---- one Lloyd iteration (sklearn _k_means_lloyd.pyx lloyd_iter_chunked_dense): label = first argmin_c (|c|^2 - 2 x.c);
+// with `update`: part[block][c][0..D-1] = sum of the centred rows of cluster c, [D] = their number -----------------------
+__global__ __launch_bounds__(64) void lloyd_kernel(const double* __restrict__ X, long long N, int D, int S,
+                                                   const double* __restrict__ mean, const double* __restrict__ Ct,
+                                                   const double* __restrict__ csq, int KP, int k, int32_t* __restrict__ labels,
+                                                   int update, double* __restrict__ part, unsigned long long* __restrict__ changed) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* tile = lds;
+  double* sums = tile + TILE * S;
+  const int D1 = D + 1;
+  int* lab = (int*)(sums + (update ? k * D1 : 0));
+  const int lane = threadIdx.x;
+  const long long total = N * D;
+  const ZK_CONST double* cm = zk_const(mean);
+  const ZK_CONST double* ct = zk_const(Ct);
+  const ZK_CONST double* cs = zk_const(csq);
+  if (update)
+    for (int e = lane; e < k * D1; e += 64) sums[e] = 0.0;
+  const int j0 = lane, j1 = lane + 64;
+  const double m0 = j0 < D ? mean[j0] : 0.0, m1 = j1 < D ? mean[j1] : 0.0;
+  unsigned long long nchg = 0;
+  for (long long tl = blockIdx.x; tl * TILE < N; tl += gridDim.x) {
+    __syncthreads();
+    tile_load(X, total, D, S, tl * TILE * D, tile, lane);
+    __syncthreads();
+    const double* row = tile + lane * S;
+    double best = std::numeric_limits<double>::infinity();
+    int bl = 0;
+    for (int c0 = 0; c0 < KP; c0 += 4) {
+      double d0, d1, d2, d3;
+      dots4(row, D, cm, ct + c0, KP, d0, d1, d2, d3);
+      const double s0 = __builtin_fma(-2.0, d0, cs[c0]), s1 = __builtin_fma(-2.0, d1, cs[c0 + 1]),
+                   s2 = __builtin_fma(-2.0, d2, cs[c0 + 2]), s3 = __builtin_fma(-2.0, d3, cs[c0 + 3]);
+      if (s0 < best) best = s0, bl = c0;
+      if (s1 < best) best = s1, bl = c0 + 1;
+      if (s2 < best) best = s2, bl = c0 + 2;
+      if (s3 < best) best = s3, bl = c0 + 3;
+    }
+    const long long r = tl * TILE + lane;
+    const bool live = r < N;
+    if (live) {
+      nchg += labels[r] != bl;
+      labels[r] = bl;
+    }
+    if (update) {
+      lab[lane] = live ? bl : -1;
+      __syncthreads();
+      const int rows = (int)(N - tl * TILE < TILE ? N - tl * TILE : TILE);
+      for (int rr = 0; rr < rows; ++rr) {
+        const int l = __builtin_amdgcn_readfirstlane(lab[rr]);
+        double* dst = sums + l * D1;
+        if (j0 <= D) {
+          const double v = j0 < D ? tile[rr * S + j0] - m0 : 1.0;
+          (void)__hip_atomic_fetch_add(dst + j0, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        if (j1 <= D) {
+          const double v = j1 < D ? tile[rr * S + j1] - m1 : 1.0;
+          (void)__hip_atomic_fetch_add(dst + j1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (update)
+    for (int e = lane; e < k * D1; e += 64) part[(long long)blockIdx.x * k * D1 + e] = sums[e];
+  if (__ballot(nchg != 0) && nchg) atomicAdd(changed, nchg);
+}
+
+// dist[r] = sum_j ((x_rj - mean_j) - centre[label_r][j])^2  (sklearn _relocate_empty_clusters_dense)
+__global__ __launch_bounds__(64) void owndist_kernel(const double* __restrict__ X, long long N, int D, int S,
+                                                     const double* __restrict__ mean, const double* __restrict__ centers,
+                                                     const int32_t* __restrict__ labels, double* __restrict__ dist) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* tile = lds;
+  const int lane = threadIdx.x;
+  const long long total = N * D;
+  const ZK_CONST double* cm = zk_const(mean);
+  for (long long tl = blockIdx.x; tl * TILE < N; tl += gridDim.x) {
+    __syncthreads();
+    tile_load(X, total, D, S, tl * TILE * D, tile, lane);
+    __syncthreads();
+    const long long r = tl * TILE + lane;
+    if (r < N) {
+      const double* row = tile + lane * S;
+      const double* c = centers + (long long)labels[r] * D;
+      double s = 0.0;
+      for (int i = 0; i < D; ++i) {
+        const double v = (row[i] - cm[i]) - c[i];
+        s += v * v;
+      }
+      dist[r] = s;
+    }
+  }
+}
+
+// ---- Gaussian mixture E step (sklearn/mixture/_gaussian_mixture.py _estimate_log_gaussian_prob + _base.py
+// _estimate_log_prob_resp): per component y = x P - mu P with P the upper-triangular Cholesky factor of the precision
+// ([k][D][DP] row-major, DP = D rounded up to 8, zeros below the diagonal and in the padding; b = mu P as [k][DP]),
+// lp_c = (-0.5 (D log 2pi + |y|^2) + logdet_c) + logw_c; log-sum-exp over components; resp (k, N) = exp(lp - lse);
+// label = first argmax; part[block] = sum of lse over the block's rows -----------------------------------------------------
+__global__ __launch_bounds__(64) void estep_kernel(const double* __restrict__ X, long long N, int D, int S, int DP,
+                                                   const double* __restrict__ P, const double* __restrict__ B,
+                                                   const double* __restrict__ cst /* [k][2]: logdet, logw */, double dlog2pi, int k,
+                                                   double* __restrict__ resp, int32_t* __restrict__ labels,
+                                                   double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* tile = lds;
+  double* lp = tile + TILE * S;  // [k][64]
+  const int lane = threadIdx.x;
+  const long long total = N * D;
+  double lse_sum = 0.0;
+  for (long long tl = blockIdx.x; tl * TILE < N; tl += gridDim.x) {
+    __syncthreads();
+    tile_load(X, total, D, S, tl * TILE * D, tile, lane);
+    __syncthreads();
+    const double* row = tile + lane * S;
+    double best = -std::numeric_limits<double>::infinity();
+    int bl = 0;
+    for (int c = 0; c < k; ++c) {
+      const ZK_CONST double* pc = zk_const(P) + (long long)c * D * DP;
+      const ZK_CONST double* bc = zk_const(B) + (long long)c * DP;
+      double sq = 0.0;
+      for (int j0 = 0; j0 < DP; j0 += 8) {
+        double a[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) a[jj] = -bc[j0 + jj];
+        const int imax = j0 + 8 < D ? j0 + 8 : D;
+        for (int i = 0; i < imax; ++i) {
+          const double x = row[i];
+          const ZK_CONST double* pr = pc + (long long)i * DP + j0;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) a[jj] = __builtin_fma(x, pr[jj], a[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) sq = __builtin_fma(a[jj], a[jj], sq);
+      }
+      const ZK_CONST double* cc = zk_const(cst) + 2 * c;
+      const double v = (-0.5 * (dlog2pi + sq) + cc[0]) + cc[1];
+      lp[c * 64 + lane] = v;
+      if (v > best) best = v, bl = c;
+    }
+    double s = 0.0;
+    for (int c = 0; c < k; ++c) s += exp(lp[c * 64 + lane] - best);
+    const double lse = log(s) + best;
+    const long long r = tl * TILE + lane;
+    if (r < N) {
+      lse_sum += lse;
+      if (labels) labels[r] = bl;
+      if (resp)
+        for (int c = 0; c < k; ++c) resp[(long long)c * N + r] = exp(lp[c * 64 + lane] - lse);
+    }
+  }
+  const double tot = wave_sum(lse_sum);
+  if (lane == 0) part[blockIdx.x] = tot;
+}
+
+// resp[c][r] = (labels[r] == c)
+__global__ __launch_bounds__(256) void onehot_kernel(const int32_t* __restrict__ labels, long long N, int k, double* __restrict__ resp) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= N) return;
+  const int l = labels[r];
+  for (int c = 0; c < k; ++c) resp[(long long)c * N + r] = l == c ? 1.0 : 0.0;
+}
+
+// part[block] = sum_r w_r [x_r - shift | 1]^T [x_r - shift | 1]  (D+1 x D+1, upper triangle of 4 x 4 register tiles; see
+// gram_kernel of zk_consumers.hip), w = one plane of the responsibilities
+__global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ X, long long N, int D, int T,
+                                                     const double* __restrict__ shift, const double* __restrict__ w,
+                                                     double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double tile[];  // [64][4T] then [64] weights
+  const int P = 4 * T;
+  double* wt = tile + 64 * P;
+  const int ti = threadIdx.x / T, tj = threadIdx.x % T;
+  const int nthreads = T * T;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (long long r0 = (long long)blockIdx.x * 64; r0 < N; r0 += (long long)gridDim.x * 64) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * P; e += nthreads) {
+      const int r = e / P, c = e - r * P;
+      double v = 0.0;
+      if (r0 + r < N) v = c < D ? X[(r0 + r) * D + c] - shift[c] : (c == D ? 1.0 : 0.0);
+      tile[e] = v;
+    }
+    for (int r = threadIdx.x; r < 64; r += nthreads) wt[r] = r0 + r < N ? w[r0 + r] : 0.0;
+    __syncthreads();
+    if (ti <= tj) {
+#pragma unroll 4
+      for (int r = 0; r < 64; ++r) {
+        const double* row = tile + r * P;
+        const double wr = wt[r];
+        double xi[4], xj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xi[a] = row[4 * ti + a] * wr, xj[a] = row[4 * tj + a];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(xi[a], xj[b], acc[a][b]);
+      }
+    }
+  }
+  const int D1 = D + 1;
+  double* out = part + (long long)blockIdx.x * D1 * D1;
+  if (ti <= tj) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = 4 * ti + a, j = 4 * tj + b;
+        if (i < D1 && j < D1 && i <= j) {
+          out[i * D1 + j] = acc[a][b];
+          if (i != j) out[j * D1 + i] = acc[a][b];
+        }
+      }
+  }
+}
+
+// ---- host helpers ------------------------------------------------------------------------------------------------
+size_t tile_lds(const zk_rows* m) { return (size_t)TILE * m->S * sizeof(double); }
+
+// persistent single-wave workgroups: as many per CU as the LDS tile allows (at most 8), never more than tiles
+int row_grid(const zk_rows* m, size_t lds_bytes) {
+  int per_cu = (int)((160 * 1024) / (lds_bytes + 512));
+  per_cu = std::max(1, std::min(per_cu, 8));
+  const long long tiles = (m->N + TILE - 1) / TILE;
+  return (int)std::min<long long>(tiles, (long long)per_cu * m->n_cu);
+}
+
+int ensure(void** buf, size_t* have, size_t need) { return zk_ensure(buf, have, need); }
+
+int upload_tab(zk_rows* m, const std::vector<double>& h) {
+  int rc = ensure(&m->d_tab, &m->tab_bytes, h.size() * sizeof(double));
+  if (rc) return rc;
+  // pageable source: the copy is complete (staged) when the call returns, and ordered before later work on the stream
+  ZK_HIP(hipMemcpyAsync(m->d_tab, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, m->stream));
+  ZK_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+int reduce_to_host(zk_rows* m, int n_blocks, int n, double* host_out) {
+  int rc = ensure(&m->d_red, &m->red_bytes, (size_t)n * sizeof(double));
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, (const double*)m->d_part, n_blocks, n,
+                     (double*)m->d_red);
+  ZK_HIP(hipGetLastError());
+  ZK_HIP(hipMemcpyAsync(host_out, m->d_red, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  ZK_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+int check_lds(size_t bytes) {
+  if (bytes > 160 * 1024) return zk_fail(ZK_E_BADARG, "too many features / clusters for one 160-KiB LDS tile");
+  return 0;
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) ZK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// the resident matrix
+// ------------------------------------------------------------------------------------------------------------------
+static int rows_init(zk_rows* m) {
+  ZK_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  (void)hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, m->device);
+  ZK_HIP(hipMalloc((void**)&m->d_mean, (size_t)m->D * sizeof(double)));
+  ZK_HIP(hipMemsetAsync(m->d_mean, 0, (size_t)m->D * sizeof(double), m->stream));
+  ZK_HIP(hipMalloc((void**)&m->d_count, 4 * sizeof(unsigned long long)));
+  ZK_HIP(hipMemsetAsync(m->d_count, 0, 4 * sizeof(unsigned long long), m->stream));
+  return 0;
+}
+
+extern "C" int zk_rows_destroy(zk_rows* m) {
+  if (!m) return 0;
+  ZK_ON_DEVICE(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  if (m->own && m->X) (void)hipFree((void*)m->X);
+  void* bufs[] = {m->d_mean, m->d_xsq, m->d_tab, m->d_part, m->d_red, m->d_seed[0], m->d_seed[1], m->d_labels, m->d_resp, m->d_count};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+  return 0;
+}
+
+static int rows_new(int device, const double* X_dev, int64_t N, int D, bool own, zk_rows** out) {
+  zk_rows* m = new zk_rows;
+  m->device = device;
+  m->N = N;
+  m->D = D;
+  m->S = D | 1;
+  m->X = X_dev;
+  m->own = own;
+  const int rc = rows_init(m);
+  if (rc) {
+    m->own = false;
+    zk_rows_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return 0;
+}
+
+static int rows_args(const void* X, int64_t N, int D, zk_rows** out) {
+  if (!X || !out) return zk_fail(ZK_E_BADARG, "null pointer");
+  if (N <= 0 || D <= 0 || D > 127) return zk_fail(ZK_E_BADARG, "need 1 <= D <= 127 features and N > 0 rows");
+  *out = nullptr;
+  return 0;
+}
+
+extern "C" int zk_rows_adopt(int device, const double* X_dev, int64_t N, int D, zk_rows** out) {
+  int rc = rows_args(X_dev, N, D, out);
+  if (rc) return rc;
+  ZK_ON_DEVICE(device);
+  return rows_new(device, X_dev, N, D, false, out);
+}
+
+extern "C" int zk_rows_create(int device, const double* X_host, int64_t N, int D, zk_rows** out) {
+  int rc = rows_args(X_host, N, D, out);
+  if (rc) return rc;
+  ZK_ON_DEVICE(device);
+  double* d = nullptr;
+  ZK_HIP(hipMalloc((void**)&d, (size_t)N * D * sizeof(double)));
+  const hipError_t e = hipMemcpy(d, X_host, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return zk_hip_fail(e, "hipMemcpy(X)");
+  }
+  rc = rows_new(device, d, N, D, true, out);
+  if (rc) (void)hipFree(d);
+  return rc;
+}
+
+extern "C" const double* zk_rows_data(const zk_rows* m) { return m ? m->X : nullptr; }
+
+// Column means (mean_out) and population variances about them (var_out), two passes as numpy.mean / numpy.var; the means
+// become the centring shift of every later k-means call; n_bad_out = rows with a non-finite element.
+extern "C" int zk_rows_center(zk_rows* m, double* mean_out, double* var_out, int64_t* n_bad_out) {
+  if (!m || !mean_out || !var_out || !n_bad_out) return zk_fail(ZK_E_BADARG, "null pointer");
+  ZK_ON_DEVICE(m->device);
+  const size_t lds = tile_lds(m);
+  int rc = check_lds(lds);
+  if (rc) return rc;
+  if ((rc = allow_lds(colsum_kernel, lds)) || (rc = allow_lds(rownorm_kernel, lds))) return rc;
+  const int grid = row_grid(m, lds);
+  if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * m->D * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)nullptr, 0,
+                     (double*)m->d_part);
+  ZK_HIP(hipGetLastError());
+  if ((rc = reduce_to_host(m, grid, m->D, mean_out))) return rc;
+  for (int j = 0; j < m->D; ++j) mean_out[j] /= (double)m->N;
+  ZK_HIP(hipMemcpyAsync(m->d_mean, mean_out, (size_t)m->D * sizeof(double), hipMemcpyHostToDevice, m->stream));
+  ZK_HIP(hipStreamSynchronize(m->stream));
+  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)m->d_mean, 1,
+                     (double*)m->d_part);
+  ZK_HIP(hipGetLastError());
+  if ((rc = reduce_to_host(m, grid, m->D, var_out))) return rc;
+  for (int j = 0; j < m->D; ++j) var_out[j] /= (double)m->N;
+  if (!m->d_xsq) ZK_HIP(hipMalloc((void**)&m->d_xsq, (size_t)m->N * sizeof(double)));
+  ZK_HIP(hipMemsetAsync(m->d_count, 0, sizeof(unsigned long long), m->stream));
+  hipLaunchKernelGGL(rownorm_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)m->d_mean,
+                     m->d_xsq, m->d_count);
+  ZK_HIP(hipGetLastError());
+  unsigned long long bad = 0;
+  ZK_HIP(hipMemcpyAsync(&bad, m->d_count, sizeof(bad), hipMemcpyDeviceToHost, m->stream));
+  ZK_HIP(hipStreamSynchronize(m->stream));
+  *n_bad_out = (int64_t)bad;
+  return 0;
+}
+
+// rows idx[0..n) of the matrix, minus the centring shift when `centred`, to the host
+extern "C" int zk_rows_fetch(zk_rows* m, const int64_t* idx, int n, int centred, double* rows_out) {
+  if (!m || !idx || !rows_out || n < 0) return zk_fail(ZK_E_BADARG, "bad arguments");
+  ZK_ON_DEVICE(m->device);
+  for (int i = 0; i < n; ++i) {
+    if (idx[i] < 0 || idx[i] >= m->N) return zk_fail(ZK_E_BADARG, "row index out of range");
+    ZK_HIP(hipMemcpyAsync(rows_out + (size_t)i * m->D, m->X + idx[i] * m->D, (size_t)m->D * sizeof(double), hipMemcpyDeviceToHost,
+                          m->stream));
+  }
+  ZK_HIP(hipStreamSynchronize(m->stream));
+  if (centred) {
+    std::vector<double> mean(m->D);
+    ZK_HIP(hipMemcpy(mean.data(), m->d_mean, (size_t)m->D * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < m->D; ++j) rows_out[(size_t)i * m->D + j] -= mean[j];
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k-means
+// ------------------------------------------------------------------------------------------------------------------
+// operand table of wave-uniform vectors: [D][KP] (vector index fastest), then their KP squared norms (+inf beyond n)
+static void pack_vectors(const double* v, int n, int D, int KP, bool pad_inf, std::vector<double>& h) {
+  h.assign((size_t)D * KP + KP, 0.0);
+  for (int c = 0; c < n; ++c) {
+    double s = 0.0;
+    for (int i = 0; i < D; ++i) {
+      const double x = v[(size_t)c * D + i];
+      h[(size_t)i * KP + c] = x;
+      s += x * x;
+    }
+    h[(size_t)D * KP + c] = s;
+  }
+  if (pad_inf)
+    for (int c = n; c < KP; ++c) h[(size_t)D * KP + c] = std::numeric_limits<double>::infinity();
+}
+
+// One seeding step: the centred candidate rows cand (t, D) with their squared norms cand_sq (t) -- the caller fetched them
+// with zk_rows_fetch and took the norms the way scikit-learn does -- against every row; with use_closest the distances are
+// folded with the current closest-distance row.  pot_out[c] = sum_r dist[c][r].
+extern "C" int zk_kmeans_seed_step(zk_rows* m, const double* cand, const double* cand_sq, int t, int use_closest, double* pot_out) {
+  if (!m || !cand || !cand_sq || !pot_out) return zk_fail(ZK_E_BADARG, "null pointer");
+  if (t < 1 || t > 8) return zk_fail(ZK_E_BADARG, "1 to 8 candidates per seeding step");
+  if (!m->d_xsq) return zk_fail(ZK_E_BADARG, "zk_rows_center first");
+  if (use_closest && !m->d_closest) return zk_fail(ZK_E_BADARG, "no closest-distance row yet");
+  ZK_ON_DEVICE(m->device);
+  const int TP = t <= 4 ? 4 : 8;
+  pack_vectors(cand, t, m->D, TP, false, m->h_buf);
+  for (int c = 0; c < t; ++c) m->h_buf[(size_t)m->D * TP + c] = cand_sq[c];
+  int rc = upload_tab(m, m->h_buf);
+  if (rc) return rc;
+  const size_t lds = tile_lds(m);
+  if ((rc = check_lds(lds))) return rc;
+  const int grid = row_grid(m, lds);
+  const int dst = use_closest ? 1 - m->seed_cur : m->seed_cur;
+  if ((rc = ensure(&m->d_seed[dst], &m->seed_bytes[dst], (size_t)8 * m->N * sizeof(double)))) return rc;
+  if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * TP * sizeof(double)))) return rc;
+  const double* tab = (const double*)m->d_tab;
+  const double* closest = use_closest ? m->d_closest : nullptr;
+  if (TP == 4) {
+    if ((rc = allow_lds(seed_kernel<4>, lds))) return rc;
+    hipLaunchKernelGGL(seed_kernel<4>, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)m->d_mean,
+                       tab, tab + (size_t)m->D * TP, t, (const double*)m->d_xsq, closest, (double*)m->d_seed[dst], (double*)m->d_part);
+  } else {
+    if ((rc = allow_lds(seed_kernel<8>, lds))) return rc;
+    hipLaunchKernelGGL(seed_kernel<8>, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)m->d_mean,
+                       tab, tab + (size_t)m->D * TP, t, (const double*)m->d_xsq, closest, (double*)m->d_seed[dst], (double*)m->d_part);
+  }
+  ZK_HIP(hipGetLastError());
+  double pot[8];
+  if ((rc = reduce_to_host(m, grid, TP, pot))) return rc;
+  for (int c = 0; c < t; ++c) pot_out[c] = pot[c];
+  m->seed_t = t;
+  m->seed_last = dst;  // seed_cur changes when zk_kmeans_seed_pick adopts one of these rows
+  m->h_buf.clear();
+  return 0;
+}
+
+// Adopt candidate `which` of the last step as the closest-distance row, then idx_out[i] = searchsorted(cumsum(closest),
+// vals[i]) (side 'left', clipped to N - 1) for the next step's draws (n_vals may be 0).
+extern "C" int zk_kmeans_seed_pick(zk_rows* m, int which, const double* vals, int n_vals, int64_t* idx_out) {
+  if (!m || m->seed_last < 0 || which < 0 || which >= m->seed_t) return zk_fail(ZK_E_BADARG, "no seeding step to pick from");
+  if (n_vals < 0 || (n_vals > 0 && (!vals || !idx_out))) return zk_fail(ZK_E_BADARG, "bad arguments");
+  ZK_ON_DEVICE(m->device);
+  m->seed_cur = m->seed_last;
+  m->d_closest = (const double*)m->d_seed[m->seed_cur] + (size_t)which * m->N;
+  if (n_vals == 0) return 0;
+  const long long nb = (m->N + 1023) / 1024;
+  int rc = ensure(&m->d_red, &m->red_bytes, (size_t)nb * sizeof(double));
+  if (rc) return rc;
+  hipLaunchKernelGGL(blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, m->stream, m->d_closest, (long long)m->N, (double*)m->d_red);
+  ZK_HIP(hipGetLastError());
+  std::vector<double> bs(nb), cum(nb), blk(1024);
+  ZK_HIP(hipMemcpyAsync(bs.data(), m->d_red, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  ZK_HIP(hipStreamSynchronize(m->stream));
+  double run = 0.0;
+  for (long long b = 0; b < nb; ++b) cum[b] = (run += bs[b]);
+  for (int i = 0; i < n_vals; ++i) {
+    long long b = std::lower_bound(cum.begin(), cum.end(), vals[i]) - cum.begin();
+    long long found = m->N;  // past the end: clipped below
+    while (b < nb && found == m->N) {
+      const long long first = b * 1024, cnt = std::min<long long>(1024, m->N - first);
+      ZK_HIP(hipMemcpy(blk.data(), m->d_closest + first, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost));
+      double s = b ? cum[b - 1] : 0.0;
+      for (long long e = 0; e < cnt; ++e) {
+        s += blk[e];
+        if (s >= vals[i]) {
+          found = first + e;
+          break;
+        }
+      }
+      ++b;
+    }
+    idx_out[i] = std::min<long long>(found, m->N - 1);
+  }
+  return 0;
+}
+
+// One Lloyd pass with the centred centres (k, D): labels are rewritten on the device; with `update` sums_out (k, D) = sum
+// of the centred rows of each cluster and counts_out (k); n_changed_out = rows whose label changed.
+extern "C" int zk_kmeans_step(zk_rows* m, const double* centers, int k, int update, double* sums_out, double* counts_out,
+                              int64_t* n_changed_out) {
+  if (!m || !centers || !n_changed_out || (update && (!sums_out || !counts_out))) return zk_fail(ZK_E_BADARG, "null pointer");
+  if (k < 1 || k > 256) return zk_fail(ZK_E_BADARG, "1 to 256 clusters");
+  ZK_ON_DEVICE(m->device);
+  const int KP = (k + 3) & ~3, D1 = m->D + 1;
+  pack_vectors(centers, k, m->D, KP, true, m->h_buf);
+  int rc = upload_tab(m, m->h_buf);
+  m->h_buf.clear();
+  if (rc) return rc;
+  const size_t lds = tile_lds(m) + (update ? (size_t)k * D1 * sizeof(double) : 0) + 64 * sizeof(int);
+  if ((rc = check_lds(lds)) || (rc = allow_lds(lloyd_kernel, lds))) return rc;
+  const int grid = row_grid(m, lds);
+  if (!m->d_labels) {
+    ZK_HIP(hipMalloc((void**)&m->d_labels, (size_t)m->N * sizeof(int32_t)));
+    ZK_HIP(hipMemsetAsync(m->d_labels, 0xff, (size_t)m->N * sizeof(int32_t), m->stream));  // -1, as sklearn's labels_old
+  }
+  if (update && (rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * k * D1 * sizeof(double)))) return rc;
+  ZK_HIP(hipMemsetAsync(m->d_count, 0, sizeof(unsigned long long), m->stream));
+  const double* tab = (const double*)m->d_tab;
+  hipLaunchKernelGGL(lloyd_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)m->d_mean, tab,
+                     tab + (size_t)m->D * KP, KP, k, m->d_labels, update, (double*)m->d_part, m->d_count);
+  ZK_HIP(hipGetLastError());
+  unsigned long long chg = 0;
+  if (update) {
+    std::vector<double> red((size_t)k * D1);
+    ZK_HIP(hipMemcpyAsync(&chg, m->d_count, sizeof(chg), hipMemcpyDeviceToHost, m->stream));
+    if ((rc = reduce_to_host(m, grid, k * D1, red.data()))) return rc;
+    for (int c = 0; c < k; ++c) {
+      for (int j = 0; j < m->D; ++j) sums_out[(size_t)c * m->D + j] = red[(size_t)c * D1 + j];
+      counts_out[c] = red[(size_t)c * D1 + m->D];
+    }
+  } else {
+    ZK_HIP(hipMemcpyAsync(&chg, m->d_count, sizeof(chg), hipMemcpyDeviceToHost, m->stream));
+    ZK_HIP(hipStreamSynchronize(m->stream));
+  }
+  *n_changed_out = (int64_t)chg;
+  return 0;
+}
+
+// forget the labels (a new run starts from labels_old = -1)
+extern "C" int zk_rows_reset_labels(zk_rows* m) {
+  if (!m) return zk_fail(ZK_E_BADARG, "null pointer");
+  ZK_ON_DEVICE(m->device);
+  if (m->d_labels) ZK_HIP(hipMemsetAsync(m->d_labels, 0xff, (size_t)m->N * sizeof(int32_t), m->stream));
+  return 0;
+}
+
+extern "C" int zk_rows_labels(zk_rows* m, int32_t* labels_host) {
+  if (!m || !labels_host) return zk_fail(ZK_E_BADARG, "null pointer");
+  if (!m->d_labels) return zk_fail(ZK_E_BADARG, "no labels yet");
+  ZK_ON_DEVICE(m->device);
+  ZK_HIP(hipMemcpyAsync(labels_host, m->d_labels, (size_t)m->N * sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+  ZK_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+extern "C" const int32_t* zk_rows_labels_dev(const zk_rows* m) { return m ? m->d_labels : nullptr; }
+
+// squared distance of every centred row to the centre of its label (k, D) -> host (N): the empty-cluster relocation
+extern "C" int zk_kmeans_own_distance(zk_rows* m, const double* centers, int k, double* dist_host) {
+  if (!m || !centers || !dist_host || k < 1) return zk_fail(ZK_E_BADARG, "bad arguments");
+  if (!m->d_labels) return zk_fail(ZK_E_BADARG, "no labels yet");
+  ZK_ON_DEVICE(m->device);
+  m->h_buf.assign(centers, centers + (size_t)k * m->D);
+  int rc = upload_tab(m, m->h_buf);
+  m->h_buf.clear();
+  if (rc) return rc;
+  const size_t lds = tile_lds(m);
+  if ((rc = check_lds(lds)) || (rc = allow_lds(owndist_kernel, lds))) return rc;
+  const int dst = 1 - m->seed_cur;  // the seeding scratch is free by now
+  if ((rc = ensure(&m->d_seed[dst], &m->seed_bytes[dst], (size_t)m->N * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(owndist_kernel, dim3(row_grid(m, lds)), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S,
+                     (const double*)m->d_mean, (const double*)m->d_tab, (const int32_t*)m->d_labels, (double*)m->d_seed[dst]);
+  ZK_HIP(hipGetLastError());
+  ZK_HIP(hipMemcpyAsync(dist_host, m->d_seed[dst], (size_t)m->N * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  ZK_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Gaussian mixture
+// ------------------------------------------------------------------------------------------------------------------
+// E step with the upper-triangular precision Cholesky factors prec_chol (k, D, D), means (k, D), log-determinants and log
+// weights (k each).  Writes the responsibilities (k, N) and the labels (first argmax) on the device;
+// lse_sum_out = sum_r logsumexp_c(weighted log prob).
+extern "C" int zk_gmm_estep(zk_rows* m, const double* prec_chol, const double* means, const double* log_det, const double* log_w, int k,
+                            int want_resp, double* lse_sum_out) {
+  if (!m || !prec_chol || !means || !log_det || !log_w || !lse_sum_out) return zk_fail(ZK_E_BADARG, "null pointer");
+  if (k < 1 || k > 64) return zk_fail(ZK_E_BADARG, "1 to 64 mixture components");
+  ZK_ON_DEVICE(m->device);
+  const int D = m->D, DP = (D + 7) & ~7;
+  std::vector<double>& h = m->h_buf;
+  h.assign((size_t)k * D * DP + (size_t)k * DP + 2 * (size_t)k, 0.0);
+  double* P = h.data();
+  double* B = P + (size_t)k * D * DP;
+  double* C = B + (size_t)k * DP;
+  for (int c = 0; c < k; ++c) {
+    const double* pc = prec_chol + (size_t)c * D * D;
+    for (int i = 0; i < D; ++i)
+      for (int j = i; j < D; ++j) P[((size_t)c * D + i) * DP + j] = pc[(size_t)i * D + j];
+    for (int j = 0; j < D; ++j) {  // (mu P)_j, the order of numpy.dot(mu, prec_chol)
+      double s = 0.0;
+      for (int i = 0; i <= j; ++i) s += means[(size_t)c * D + i] * pc[(size_t)i * D + j];
+      B[(size_t)c * DP + j] = s;
+    }
+    C[2 * c] = log_det[c];
+    C[2 * c + 1] = log_w[c];
+  }
+  int rc = upload_tab(m, h);
+  h.clear();
+  if (rc) return rc;
+  const size_t lds = tile_lds(m) + (size_t)k * 64 * sizeof(double);
+  if ((rc = check_lds(lds)) || (rc = allow_lds(estep_kernel, lds))) return rc;
+  const int grid = row_grid(m, lds);
+  if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * sizeof(double)))) return rc;
+  if (want_resp && (rc = ensure(&m->d_resp, &m->resp_bytes, (size_t)k * m->N * sizeof(double)))) return rc;
+  if (!m->d_labels) ZK_HIP(hipMalloc((void**)&m->d_labels, (size_t)m->N * sizeof(int32_t)));
+  const double* tab = (const double*)m->d_tab;
+  hipLaunchKernelGGL(estep_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, D, m->S, DP, tab, tab + (size_t)k * D * DP,
+                     tab + (size_t)k * D * DP + (size_t)k * DP, (double)D * std::log(2.0 * M_PI), k,
+                     want_resp ? (double*)m->d_resp : nullptr, m->d_labels, (double*)m->d_part);
+  ZK_HIP(hipGetLastError());
+  return reduce_to_host(m, grid, 1, lse_sum_out);
+}
+
+// responsibilities = one-hot of the current labels (the k-means initialisation of the mixture)
+extern "C" int zk_gmm_resp_from_labels(zk_rows* m, int k) {
+  if (!m || k < 1 || k > 64) return zk_fail(ZK_E_BADARG, "bad arguments");
+  if (!m->d_labels) return zk_fail(ZK_E_BADARG, "no labels yet");
+  ZK_ON_DEVICE(m->device);
+  int rc = ensure(&m->d_resp, &m->resp_bytes, (size_t)k * m->N * sizeof(double));
+  if (rc) return rc;
+  hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)((m->N + 255) / 256)), dim3(256), 0, m->stream, (const int32_t*)m->d_labels,
+                     (long long)m->N, k, (double*)m->d_resp);
+  ZK_HIP(hipGetLastError());
+  return 0;
+}
+
+// M-step sums of component c about `shift` (D): gram_out (D+1, D+1) = sum_r resp[c][r] [x_r - shift | 1]^T [x_r - shift | 1]
+// -- second moments, first moments in the last row / column, the component's weight in the corner.
+extern "C" int zk_gmm_moments(zk_rows* m, int c, const double* shift, double* gram_out) {
+  if (!m || !shift || !gram_out) return zk_fail(ZK_E_BADARG, "null pointer");
+  if (!m->d_resp || c < 0 || (size_t)(c + 1) * m->N * sizeof(double) > m->resp_bytes) return zk_fail(ZK_E_BADARG, "no such component");
+  ZK_ON_DEVICE(m->device);
+  const int D = m->D, D1 = D + 1, T = (D1 + 3) / 4;
+  m->h_buf.assign(shift, shift + D);
+  int rc = upload_tab(m, m->h_buf);
+  m->h_buf.clear();
+  if (rc) return rc;
+  long long blocks = (m->N + 63) / 64;
+  if (blocks > 2LL * m->n_cu) blocks = 2LL * m->n_cu;
+  if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)blocks * D1 * D1 * sizeof(double)))) return rc;
+  const size_t lds = ((size_t)64 * 4 * T + 64) * sizeof(double);
+  if ((rc = allow_lds(wgram_kernel, lds))) return rc;
+  hipLaunchKernelGGL(wgram_kernel, dim3((unsigned)blocks), dim3(T * T), lds, m->stream, m->X, (long long)m->N, D, T, (const double*)m->d_tab,
+                     (const double*)m->d_resp + (size_t)c * m->N, (double*)m->d_part);
+  ZK_HIP(hipGetLastError());
+  return reduce_to_host(m, (int)blocks, D1 * D1, gram_out);
+}

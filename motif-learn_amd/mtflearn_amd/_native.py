@@ -90,6 +90,22 @@ SYMBOLS = {
                            c_int]),
     "zk_gram_dev": (c_int, [c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "zk_project_dev": (c_int, [c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "zk_rows_create": (c_int, [c_int, POINTER(c_double), c_int64, c_int, POINTER(c_void_p)]),
+    "zk_rows_adopt": (c_int, [c_int, c_void_p, c_int64, c_int, POINTER(c_void_p)]),
+    "zk_rows_destroy": (c_int, [c_void_p]),
+    "zk_rows_data": (c_void_p, [c_void_p]),
+    "zk_rows_center": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "zk_rows_fetch": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, POINTER(c_double)]),
+    "zk_rows_reset_labels": (c_int, [c_void_p]),
+    "zk_rows_labels": (c_int, [c_void_p, POINTER(c_int32)]),
+    "zk_rows_labels_dev": (c_void_p, [c_void_p]),
+    "zk_kmeans_seed_step": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), c_int, c_int, POINTER(c_double)]),
+    "zk_kmeans_seed_pick": (c_int, [c_void_p, c_int, POINTER(c_double), c_int, POINTER(c_int64)]),
+    "zk_kmeans_step": (c_int, [c_void_p, POINTER(c_double), c_int, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "zk_kmeans_own_distance": (c_int, [c_void_p, POINTER(c_double), c_int, POINTER(c_double)]),
+    "zk_gmm_estep": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), c_int, c_int, POINTER(c_double)]),
+    "zk_gmm_resp_from_labels": (c_int, [c_void_p, c_int]),
+    "zk_gmm_moments": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_double)]),
     "zk_device_malloc": (c_int, [c_int, c_int64, POINTER(c_void_p)]),
     "zk_device_free": (c_int, [c_int, c_void_p]),
     "zk_device_copy": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int]),

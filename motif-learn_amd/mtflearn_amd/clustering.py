@@ -1,0 +1,392 @@
+"""Clustering consumers of the moment matrix on the GPU -- the mirror of ``mtflearn.clustering``.
+
+``kmeans_lbs(X, n, random_state)`` and ``gmm_lbs(X, n, type, ramdom_state)`` replace the reference's wrappers
+(``mtflearn/clustering/_clustering_functions.py:8-22, 25-33``): scikit-learn's ``KMeans(n, random_state).fit(X).labels_``
+and ``GaussianMixture(n, covariance_type, random_state).fit(X).predict(X)``, each followed by the reference's relabelling by
+cluster size.  The ``(N, D)`` matrix is uploaded once (or adopted where it already is: ``DeviceRows.adopt``) and every pass
+over it -- squared distances to seeding candidates, Lloyd assignment with the per-cluster sums, the mixture's E step and the
+weighted second moments of its M step -- is a kernel of ``csrc/zk_cluster.hip``.  What happens between passes is
+scikit-learn's own control flow, restated here on ``k x D``-sized arrays: the k-means++ draws from the caller's
+``RandomState`` (same calls in the same order, so the same candidates), centre averaging, the centre-shift / strict
+convergence tests, empty-cluster relocation, Cholesky factors of the covariances (SciPy), the lower-bound test.  References
+are to scikit-learn 1.7 (``sklearn/cluster/_kmeans.py``, ``_k_means_lloyd.pyx``, ``_k_means_common.pyx``,
+``sklearn/mixture/_base.py``, ``_gaussian_mixture.py``), a dependency of the reference and of this package: parity is tested
+against it directly, and against labels captured from the reference's own two functions (``tests/golden``).
+
+Arithmetic differs from scikit-learn's only in summation order (its BLAS / OpenMP reductions are not reproducible from run
+to run either); a label can differ where a point is equidistant from two centres to the last bits.  float32 input is
+promoted to float64 (scikit-learn would cluster float32 data in single precision).
+"""
+from __future__ import annotations
+
+import warnings
+from ctypes import POINTER, byref, c_double, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+from . import _native
+from .features.pickers import _device
+
+__all__ = ["kmeans_lbs", "gmm_lbs", "sort_lbs", "DeviceRows", "kmeans_fit", "gmm_fit_predict"]
+
+_PD = POINTER(c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(_PD)
+
+
+class DeviceRows:
+    """A float64 matrix ``(N, D)``, ``D <= 127``, resident on one GPU with the work buffers of the clustering passes."""
+
+    def __init__(self, X=None, device=None, _adopt=None):
+        self._lib = _native.load()
+        if _native.device_count() == 0:
+            raise RuntimeError("no HIP device visible: mtflearn_amd computes on MI355X only (there is no CPU fallback)")
+        self.device = _device() if device is None else int(device)
+        handle = c_void_p()
+        if _adopt is not None:
+            ptr, n, d = _adopt
+            _native.check(self._lib.zk_rows_adopt(self.device, c_void_p(ptr), n, d, byref(handle)), "zk_rows_adopt")
+        else:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            if X.ndim != 2:
+                raise ValueError(f"Expected 2D array, got {X.ndim}D array instead")
+            n, d = X.shape
+            if n == 0 or d == 0:
+                raise ValueError(f"Found array with {n} sample(s) and {d} feature(s) while a minimum of 1 is required.")
+            _native.check(self._lib.zk_rows_create(self.device, _p(X), n, d, byref(handle)), "zk_rows_create")
+        self._h = handle
+        self.n_rows, self.n_features = int(n), int(d)
+        self._stats = None
+
+    @classmethod
+    def adopt(cls, device_pointer, n_rows, n_features, device=None):
+        """Borrow a matrix that already lives in device memory (e.g. the output of ``zk_transform_patches_dev``)."""
+        return cls(device=device, _adopt=(int(device_pointer), int(n_rows), int(n_features)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.zk_rows_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- passes ----------------------------------------------------------------------------------------------------
+    def center(self):
+        """(column means, population variances, number of rows with a non-finite element); cached."""
+        if self._stats is None:
+            mean, var, bad = np.empty(self.n_features), np.empty(self.n_features), c_int64()
+            _native.check(self._lib.zk_rows_center(self._h, _p(mean), _p(var), byref(bad)), "zk_rows_center")
+            self._stats = (mean, var, int(bad.value))
+        return self._stats
+
+    def fetch(self, idx, centred=True):
+        idx = np.ascontiguousarray(idx, dtype=np.int64).ravel()
+        out = np.empty((len(idx), self.n_features))
+        _native.check(self._lib.zk_rows_fetch(self._h, idx.ctypes.data_as(POINTER(c_int64)), len(idx), int(centred), _p(out)),
+                      "zk_rows_fetch")
+        return out
+
+    def seed_step(self, cand, cand_sq, use_closest):
+        cand, cand_sq = np.ascontiguousarray(cand), np.ascontiguousarray(cand_sq)
+        pot = np.empty(len(cand))
+        _native.check(self._lib.zk_kmeans_seed_step(self._h, _p(cand), _p(cand_sq), len(cand), int(use_closest), _p(pot)),
+                      "zk_kmeans_seed_step")
+        return pot
+
+    def seed_pick(self, which, vals=()):
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        idx = np.empty(len(vals), dtype=np.int64)
+        _native.check(self._lib.zk_kmeans_seed_pick(self._h, int(which), _p(vals), len(vals), idx.ctypes.data_as(POINTER(c_int64))),
+                      "zk_kmeans_seed_pick")
+        return idx
+
+    def reset_labels(self):
+        _native.check(self._lib.zk_rows_reset_labels(self._h), "zk_rows_reset_labels")
+
+    def lloyd(self, centers, update=True):
+        centers = np.ascontiguousarray(centers)
+        k = len(centers)
+        sums, counts, changed = np.empty((k, self.n_features)), np.empty(k), c_int64()
+        _native.check(self._lib.zk_kmeans_step(self._h, _p(centers), k, int(update), _p(sums), _p(counts), byref(changed)),
+                      "zk_kmeans_step")
+        return sums, counts, int(changed.value)
+
+    def own_distance(self, centers):
+        centers = np.ascontiguousarray(centers)
+        out = np.empty(self.n_rows)
+        _native.check(self._lib.zk_kmeans_own_distance(self._h, _p(centers), len(centers), _p(out)), "zk_kmeans_own_distance")
+        return out
+
+    def labels(self):
+        out = np.empty(self.n_rows, dtype=np.int32)
+        _native.check(self._lib.zk_rows_labels(self._h, out.ctypes.data_as(POINTER(c_int32))), "zk_rows_labels")
+        return out
+
+    def estep(self, prec_chol, means, log_det, log_w, want_resp=True):
+        prec_chol, means = np.ascontiguousarray(prec_chol), np.ascontiguousarray(means)
+        log_det, log_w = np.ascontiguousarray(log_det), np.ascontiguousarray(log_w)
+        total = c_double()
+        _native.check(self._lib.zk_gmm_estep(self._h, _p(prec_chol), _p(means), _p(log_det), _p(log_w), len(means),
+                                             int(want_resp), byref(total)), "zk_gmm_estep")
+        return total.value
+
+    def resp_from_labels(self, k):
+        _native.check(self._lib.zk_gmm_resp_from_labels(self._h, int(k)), "zk_gmm_resp_from_labels")
+
+    def moments(self, component, shift):
+        shift = np.ascontiguousarray(shift)
+        d1 = self.n_features + 1
+        out = np.empty((d1, d1))
+        _native.check(self._lib.zk_gmm_moments(self._h, int(component), _p(shift), _p(out)), "zk_gmm_moments")
+        return out
+
+
+def _as_rows(X):
+    return (X, False) if isinstance(X, DeviceRows) else (DeviceRows(X), True)
+
+
+def _check_finite(rows):
+    if rows.center()[2]:
+        raise ValueError("Input X contains NaN or infinity.")
+
+
+# ---------------------------------------------------------------------------------------------------------- k-means
+def _row_norms_sq(a):
+    return np.einsum("ij,ij->i", a, a)                                       # sklearn.utils.extmath.row_norms(squared=True)
+
+
+def _kmeans_plusplus(rows, n_clusters, random_state):
+    """``_kmeans_plusplus`` (sklearn/cluster/_kmeans.py) on the centred matrix: same draws, distances on the device."""
+    n = rows.n_rows
+    n_local_trials = 2 + int(np.log(n_clusters))
+    centers = np.empty((n_clusters, rows.n_features))
+    indices = np.full(n_clusters, -1, dtype=int)
+    weight = np.ones(n)
+    center_id = random_state.choice(n, p=weight / weight.sum())
+    centers[0] = rows.fetch([center_id])[0]
+    indices[0] = center_id
+    current_pot = rows.seed_step(centers[:1], _row_norms_sq(centers[:1]), use_closest=False)[0]
+    which = 0
+    for c in range(1, n_clusters):
+        rand_vals = random_state.uniform(size=n_local_trials) * current_pot
+        candidate_ids = rows.seed_pick(which, rand_vals)                     # searchsorted(stable_cumsum(closest), rand_vals)
+        cand = rows.fetch(candidate_ids)
+        pots = rows.seed_step(cand, _row_norms_sq(cand), use_closest=True)
+        which = int(np.argmin(pots))
+        current_pot = pots[which]
+        centers[c] = cand[which]
+        indices[c] = candidate_ids[which]
+    return centers, indices
+
+
+def _relocate_empty_clusters(rows, centers_old, centers_new, counts):
+    """``_relocate_empty_clusters_dense`` (sklearn/cluster/_k_means_common.pyx): the points farthest from their centres
+    become the centres of the empty clusters; labels are left as they are."""
+    empty = np.where(counts == 0)[0]
+    if len(empty) == 0:
+        return
+    distances = rows.own_distance(centers_old)
+    far = np.argpartition(distances, -len(empty))[:-len(empty) - 1:-1]
+    labels = rows.labels()
+    points = rows.fetch(far)
+    for new_id, far_idx, x in zip(empty, far, points):
+        old_id = labels[far_idx]
+        centers_new[old_id] -= x
+        centers_new[new_id] = x
+        counts[new_id] = 1.0
+        counts[old_id] -= 1.0
+
+
+def kmeans_fit(X, n_clusters, random_state=0, max_iter=300, tol=1e-4):
+    """``KMeans(n_clusters, random_state=random_state)`` with scikit-learn's defaults (k-means++ seeding, one run, Lloyd):
+    returns ``(labels int32 (N), cluster_centers (k, D), n_iter)``.  ``X``: array or ``DeviceRows``."""
+    from sklearn.utils import check_random_state
+    rows, own = _as_rows(X)
+    try:
+        if not isinstance(n_clusters, (int, np.integer)) or n_clusters < 1:
+            raise ValueError(f"The 'n_clusters' parameter of KMeans must be an int in the range [1, inf). Got {n_clusters!r} instead.")
+        if rows.n_rows < n_clusters:
+            raise ValueError(f"n_samples={rows.n_rows} should be >= n_clusters={n_clusters}.")
+        if n_clusters > 256:
+            raise ValueError("at most 256 clusters on the device")
+        _check_finite(rows)
+        mean, var, _ = rows.center()
+        tol_abs = np.mean(var) * tol                                         # _tolerance(X, tol)
+        rs = check_random_state(random_state)
+        centers, _ = _kmeans_plusplus(rows, n_clusters, rs)
+        rows.reset_labels()
+        strict = False
+        n_iter = 0
+        for n_iter in range(1, max_iter + 1):                                # _kmeans_single_lloyd
+            sums, counts, n_changed = rows.lloyd(centers, update=True)
+            _relocate_empty_clusters(rows, centers, sums, counts)
+            centers_new = sums
+            filled = counts > 0
+            centers_new[filled] *= (1.0 / counts[filled])[:, None]           # _average_centers
+            shift = np.sqrt(((centers_new - centers) ** 2).sum(axis=1))      # _center_shift
+            centers = centers_new
+            if n_changed == 0:
+                strict = True
+                break
+            if (shift ** 2).sum() <= tol_abs:
+                break
+        if not strict:
+            rows.lloyd(centers, update=False)                                # labels consistent with the final centres
+        labels = rows.labels()
+        if len(np.unique(labels)) < n_clusters:
+            from sklearn.exceptions import ConvergenceWarning
+            warnings.warn(f"Number of distinct clusters ({len(np.unique(labels))}) found smaller than n_clusters "
+                          f"({n_clusters}). Possibly due to duplicate points in X.", ConvergenceWarning, stacklevel=2)
+        return labels, centers + mean, n_iter
+    finally:
+        if own:
+            rows.close()
+
+
+def _relabel_by_size(lbs):
+    """The reference's relabelling (``_clustering_functions.py:17-21`` / ``28-32``), with its dictionary built the same way:
+    ``dict(zip(argsort(counts)[::-1], unique))`` applied to every label."""
+    present = np.bincount(lbs)
+    unique = np.flatnonzero(present).astype(lbs.dtype)                       # np.unique(lbs, return_counts=True)
+    counts = present[unique]
+    lbs_order = np.argsort(counts)[::-1]
+    order_dict = dict(zip(lbs_order, unique))
+    if all(u in order_dict for u in unique):
+        lut = np.zeros(len(present), dtype=lbs.dtype)                        # the values are elements of `unique`
+        for key, value in order_dict.items():
+            lut[key] = value
+        return lut[lbs]
+    return np.vectorize(order_dict.get)(lbs)             # a label without a cluster: the reference's own call (raises)
+
+
+def kmeans_lbs(X, n=None, random_state=0):
+    """Drop-in for ``mtflearn.clustering.kmeans_lbs`` (reference ``_clustering_functions.py:8-22``)."""
+    labels, _, _ = kmeans_fit(X, n, random_state=random_state)
+    return _relabel_by_size(labels)
+
+
+def sort_lbs(lbs):
+    """``mtflearn.clustering.sort_lbs`` (reference ``_clustering_functions.py:36-43``): labels renumbered by decreasing size."""
+    unique_lbs, counts = np.unique(lbs, return_counts=True)
+    unique_lbs = unique_lbs[np.argsort(counts)[::-1]]
+    lut = dict(zip(unique_lbs.tolist(), range(len(unique_lbs))))
+    return np.vectorize(lut.get)(lbs)
+
+
+# ------------------------------------------------------------------------------------------------- Gaussian mixture
+_CHOL_ERROR = ("Fitting the mixture model failed because some components have ill-defined empirical covariance (for instance "
+               "caused by singleton or collapsed samples). Try to decrease the number of components, increase reg_covar, or "
+               "scale the input data.")
+
+
+def _gaussian_parameters(rows, k, shift, reg_covar, covariance_type):
+    """``_estimate_gaussian_parameters`` (sklearn/mixture/_gaussian_mixture.py) from the device's weighted moments about
+    ``shift``: (nk, means, covariances)."""
+    d = rows.n_features
+    eps10 = 10 * np.finfo(np.float64).eps
+    nk, means = np.empty(k), np.empty((k, d))
+    scatter = np.empty((k, d, d))                                             # sum_r w (x - mean)(x - mean)^T
+    for c in range(k):
+        g = rows.moments(c, shift)
+        a, b, n0 = g[:d, :d], g[d, :d], g[d, d]
+        nk[c] = n0 + eps10
+        mt = b / nk[c]
+        means[c] = shift + mt
+        scatter[c] = a - np.outer(mt, b) - np.outer(b, mt) + n0 * np.outer(mt, mt)
+    if covariance_type == "full":
+        cov = scatter / nk[:, None, None]
+        cov[:, np.arange(d), np.arange(d)] += reg_covar
+    elif covariance_type == "tied":
+        cov = scatter.sum(axis=0) / nk.sum()
+        cov[np.arange(d), np.arange(d)] += reg_covar
+    elif covariance_type == "diag":
+        cov = scatter[:, np.arange(d), np.arange(d)] / nk[:, None] + reg_covar
+    elif covariance_type == "spherical":
+        cov = (scatter[:, np.arange(d), np.arange(d)] / nk[:, None] + reg_covar).mean(axis=1)
+    else:
+        raise ValueError(f"The 'covariance_type' parameter of GaussianMixture must be a str among "
+                         f"{{'full', 'tied', 'diag', 'spherical'}}. Got {covariance_type!r} instead.")
+    return nk, means, cov
+
+
+def _precision_cholesky(cov, covariance_type, k, d):
+    """``_compute_precision_cholesky`` -> upper-triangular factors (k, D, D) for the E-step kernel + ``log_det``."""
+    from scipy import linalg
+    out = np.zeros((k, d, d))
+
+    def chol(c):
+        try:
+            low = linalg.cholesky(c, lower=True)
+        except linalg.LinAlgError:
+            raise ValueError(_CHOL_ERROR)
+        return linalg.solve_triangular(low, np.eye(d), lower=True).T
+
+    if covariance_type == "full":
+        for c in range(k):
+            out[c] = chol(cov[c])
+    elif covariance_type == "tied":
+        out[:] = chol(cov)
+    else:
+        if np.any(np.less_equal(cov, 0.0)):
+            raise ValueError(_CHOL_ERROR)
+        diag = 1.0 / np.sqrt(cov)
+        out[:, np.arange(d), np.arange(d)] = diag if covariance_type == "diag" else diag[:, None]
+    log_det = np.sum(np.log(out[:, np.arange(d), np.arange(d)]), axis=1)     # _compute_log_det_cholesky
+    return out, log_det
+
+
+def gmm_fit_predict(X, n_components, covariance_type="full", random_state=0, tol=1e-3, reg_covar=1e-6, max_iter=100):
+    """``GaussianMixture(n_components, covariance_type=..., random_state=...).fit(X).predict(X)`` with scikit-learn's defaults
+    (k-means initialisation, one run): returns ``(labels int32 (N), n_iter, converged)``."""
+    from sklearn.utils import check_random_state
+    rows, own = _as_rows(X)
+    try:
+        k, d, n = int(n_components), rows.n_features, rows.n_rows
+        if n < 2:
+            raise ValueError(f"Found array with {n} sample(s) (shape=({n}, {d})) while a minimum of 2 is required by GaussianMixture.")
+        if n < k:
+            raise ValueError(f"Expected n_samples >= n_components but got n_components = {k}, n_samples = {n}")
+        if k > 64:
+            raise ValueError("at most 64 mixture components on the device")
+        _check_finite(rows)
+        shift = rows.center()[0]
+        rs = check_random_state(random_state)
+        kmeans_fit(rows, k, random_state=rs)                                 # _initialize_parameters, init_params='kmeans'
+        rows.resp_from_labels(k)
+        weights, means, cov = _gaussian_parameters(rows, k, shift, reg_covar, covariance_type)
+        weights /= n
+        prec, log_det = _precision_cholesky(cov, covariance_type, k, d)
+        lower_bound, converged, n_iter = -np.inf, False, 0
+        for n_iter in range(1, max_iter + 1):
+            prev = lower_bound
+            lower_bound = rows.estep(prec, means, log_det, np.log(weights)) / n
+            weights, means, cov = _gaussian_parameters(rows, k, shift, reg_covar, covariance_type)
+            weights /= weights.sum()
+            prec, log_det = _precision_cholesky(cov, covariance_type, k, d)
+            if abs(lower_bound - prev) < tol:
+                converged = True
+                break
+        if not converged and max_iter > 0:
+            from sklearn.exceptions import ConvergenceWarning
+            warnings.warn("Best performing initialization did not converge. Try different init parameters, or increase "
+                          "max_iter, tol, or check for degenerate data.", ConvergenceWarning, stacklevel=2)
+        rows.estep(prec, means, log_det, np.log(weights), want_resp=False)   # the final E step = predict(X)
+        return rows.labels(), n_iter, converged
+    finally:
+        if own:
+            rows.close()
+
+
+def gmm_lbs(X, n, type="full", ramdom_state=0):
+    """Drop-in for ``mtflearn.clustering.gmm_lbs`` (reference ``_clustering_functions.py:25-33``; the keyword is spelt
+    ``ramdom_state`` there)."""
+    labels, _, _ = gmm_fit_predict(X, n, covariance_type=type, random_state=ramdom_state)
+    return _relabel_by_size(labels.astype(np.intp))                          # predict() = argmax: numpy's index type

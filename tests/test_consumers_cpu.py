@@ -1,0 +1,43 @@
+"""Host pieces of the clustering consumers (no GPU): the reference's relabelling by cluster size against labels captured
+from the reference (tests/golden/consumers_golden.npz, oracle/make_golden_consumers.py)."""
+import os
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "consumers_golden.npz"))
+
+
+def test_sort_lbs_matches_reference(golden):
+    from mtflearn_amd.clustering import sort_lbs
+    got = sort_lbs(golden["sort_in"])
+    assert got.dtype == golden["sort_out"].dtype
+    np.testing.assert_array_equal(got, golden["sort_out"])
+
+
+def test_relabel_by_size_is_the_reference_mapping(golden):
+    """Applied to scikit-learn's own labels (what the reference feeds it) the mapping reproduces the reference's output."""
+    from sklearn.cluster import KMeans
+    from mtflearn_amd.clustering import _relabel_by_size
+    for key, n in (("Xa", 4), ("Xb", 5)):
+        lbs = KMeans(n_clusters=n, random_state=0).fit(golden[key]).labels_
+        np.testing.assert_array_equal(_relabel_by_size(lbs), golden[f"kmeans_{key}_{n}"])
+    # the largest cluster becomes 0, sizes descend
+    out = _relabel_by_size(np.array([2, 2, 2, 0, 1, 1], dtype=np.int32))
+    np.testing.assert_array_equal(out, [0, 0, 0, 2, 1, 1])
+    # a missing label makes the reference's dictionary lookup return None, on which its np.vectorize call raises:
+    # reproduced (same call), not repaired
+    with pytest.raises(TypeError):
+        _relabel_by_size(np.array([0, 0, 2], dtype=np.int32))
+
+
+def test_no_gpu_means_an_error_not_a_fallback(golden):
+    from mtflearn_amd import _native
+    from mtflearn_amd.clustering import kmeans_lbs
+    if _native.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        kmeans_lbs(golden["Xa"], 4)

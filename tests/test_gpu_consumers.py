@@ -31,3 +31,88 @@ def test_pca_matches_sklearn_on_a_moment_matrix():
         pca(X, n_components=46)
     with pytest.raises(ValueError, match="Expected 2D array"):
         pca(np.zeros(5))
+
+
+@pytest.fixture(scope="module")
+def consumers_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "consumers_golden.npz"))
+
+
+def test_clustering_labels_match_the_reference(consumers_golden):
+    """kmeans_lbs / gmm_lbs on the device against labels captured from the reference's own two functions
+    (clustering/_clustering_functions.py:8-33, oracle/make_golden_consumers.py)."""
+    from mtflearn_amd.clustering import kmeans_lbs, gmm_lbs
+    g = consumers_golden
+    for key in g.files:
+        parts = key.split("_")
+        if parts[0] == "kmeans":
+            X, n = g[parts[1]], int(parts[2])
+            got = kmeans_lbs(X, n, random_state=7) if key.endswith("rs7") else kmeans_lbs(X, n)
+        elif parts[0] == "gmm":
+            X, n = g[parts[1]], int(parts[2])
+            got = gmm_lbs(X, n, type=parts[3])
+        else:
+            continue
+        assert got.dtype == g[key].dtype and got.shape == g[key].shape, key
+        np.testing.assert_array_equal(got, g[key], err_msg=key)
+
+
+def _moment_matrix(n_max=8, step=2, noise=True):
+    from mtflearn_amd import ZPs
+    from mtflearn_amd.synthetic import honeycomb_frame, sliding_patches
+    frame = honeycomb_frame(320, seed=11, noise=noise)
+    patches = sliding_patches(frame, 32, rows=range(0, 288, step), cols=range(0, 288, step))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return ZPs(n_max, 32).transform(patches).data
+
+
+def test_kmeans_matches_sklearn_on_moment_matrices():
+    """Overlapping clusters (tens of Lloyd iterations), several k and seeds, 45 and 91 features: labels and centres against
+    scikit-learn's KMeans itself.  A label may differ only where two centres are equidistant to rounding."""
+    from sklearn.cluster import KMeans
+    from mtflearn_amd.clustering import kmeans_fit, DeviceRows
+    X = _moment_matrix()
+    rng = np.random.default_rng(1)
+    cases = [(X, 3, 0), (X, 6, 1), (X, 9, 5), (_moment_matrix(12, 3, False), 4, 0),
+             (rng.standard_normal((5000, 3)), 8, 2), (rng.standard_normal((777, 127)) + 3.0, 5, 0),
+             (rng.standard_normal((300, 64)), 17, 3), (rng.standard_normal((64, 2)), 1, 0)]
+    for data, k, seed in cases:
+        model = KMeans(n_clusters=k, random_state=seed).fit(data)
+        labels, centers, n_iter = kmeans_fit(data, k, random_state=seed)
+        agree = np.mean(labels == model.labels_)
+        assert agree >= 0.999, (data.shape, k, seed, agree, n_iter, model.n_iter_)
+        np.testing.assert_allclose(centers, model.cluster_centers_, rtol=0, atol=1e-6 * np.abs(model.cluster_centers_).max())
+        assert n_iter == model.n_iter_
+    # a resident matrix is clustered repeatedly without another upload; float32 input is promoted
+    with DeviceRows(X.astype(np.float32)) as rows:
+        a = kmeans_fit(rows, 4, random_state=0)[0]
+        b = kmeans_fit(rows, 4, random_state=0)[0]
+        np.testing.assert_array_equal(a, b)
+    ref = KMeans(n_clusters=4, random_state=0).fit(X.astype(np.float32).astype(np.float64)).labels_
+    assert np.mean(a == ref) >= 0.999
+    with pytest.raises(ValueError, match="should be >= n_clusters"):
+        kmeans_fit(X[:3], 5)
+    bad = X[:100].copy()
+    bad[7, 3] = np.nan
+    with pytest.raises(ValueError, match="NaN"):
+        kmeans_fit(bad, 2)
+
+
+def test_gmm_matches_sklearn_on_moment_matrices():
+    from sklearn.mixture import GaussianMixture
+    from mtflearn_amd.clustering import gmm_fit_predict
+    X = _moment_matrix()
+    pcs = X @ np.linalg.svd(X - X.mean(0), full_matrices=False)[2][:12].T            # 12 leading components: well-conditioned
+    rng = np.random.default_rng(3)
+    blobs = np.concatenate([rng.standard_normal((3000, 20)) * s + c for s, c in ((1.0, 0.0), (0.5, 3.0), (2.0, -4.0))])
+    for data, k, kind in [(pcs, 3, "full"), (pcs, 4, "diag"), (pcs, 3, "tied"), (pcs, 3, "spherical"), (blobs, 3, "full"),
+                          (blobs, 5, "full"), (X, 2, "full")]:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = GaussianMixture(k, covariance_type=kind, random_state=0).fit(data)
+            ref = model.predict(data)
+            labels, n_iter, converged = gmm_fit_predict(data, k, covariance_type=kind, random_state=0)
+        assert np.mean(labels == ref) >= 0.999, (data.shape, k, kind, np.mean(labels == ref), n_iter, model.n_iter_)
+        assert n_iter == model.n_iter_ and converged == model.converged_
