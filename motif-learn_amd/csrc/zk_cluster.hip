@@ -6,10 +6,11 @@
 // in the Python wrapper (mtflearn_amd/features/consumers.py).
 //
 // Common shape of the row kernels: a workgroup is ONE wave that owns tiles of 64 consecutive rows.  A tile is 64*D
-// contiguous doubles: it is copied with coalesced loads into LDS (row stride S = D | 1 doubles, so that the later
-// lane = row reads are conflict-free), then lane r walks its row while everything that is not a matrix element -- centre
-// coordinates, Cholesky factors, column means -- is wave-uniform and arrives through scalar loads (as in the moment
-// kernels).  Column sums per cluster are built the other way round (lane = column, the row's label wave-uniform) with
+// contiguous doubles = 32*D granules of 16 B: the LDS-DMA engine copies it as it lies (global_load_lds_dwordx4, 1 KiB per
+// instruction, no VGPRs) into one of the wave's two LDS buffers while the wave computes on the other (tile_pipe).  Then
+// lane r walks row r (stride D doubles: conflict-free for odd D, i.e. for n_max 8 / 12 moment matrices) while everything
+// that is not a matrix element -- centre coordinates, Cholesky factors, column means -- is wave-uniform and arrives through
+// scalar loads (as in the moment kernels).  Column sums per cluster are built the other way round (lane = column, the row's label wave-uniform) with
 // LDS floating-point adds into a wave-private table.  Per-workgroup partial results are written out and summed by a second
 // kernel in a fixed order: results do not depend on scheduling (bit-identical from run to run on the same device).
 #include "zk_internal.h"
@@ -17,13 +18,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 struct zk_rows {
   int device = 0;
   int n_cu = 256;
   int64_t N = 0;
-  int D = 0, S = 0;
+  int D = 0;
   const double* X = nullptr;
   bool own = false;
   hipStream_t stream = nullptr;
@@ -52,22 +54,60 @@ namespace {
 
 constexpr int TILE = 64;
 
-__device__ __forceinline__ void tile_load(const double* __restrict__ X, long long total, int D, int S, long long base,
-                                          double* __restrict__ tile, int lane) {
-  int row = lane / D, col = lane - row * D;
-  const int adv_row = TILE / D, adv_col = TILE - adv_row * D;
-#pragma unroll 8
-  for (int q = 0; q < D; ++q) {
-    const long long e = base + (long long)q * TILE + lane;
-    tile[row * S + col] = e < total ? __builtin_nontemporal_load(X + e) : 0.0;
-    row += adv_row;
-    col += adv_col;
-    if (col >= D) {
-      col -= D;
-      ++row;
+#define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// The wave's stream of tiles t = blockIdx.x, + gridDim.x, ...: acquire() returns tile t in LDS (row r at [r * D]) once its
+// DMA has landed and puts the DMA of the next tile in flight into the other buffer; advance() moves on.  Only tiles that lie
+// wholly inside the matrix are moved by DMA (whole 16-B granules); the ragged last tile is copied with ordinary loads, rows
+// past the end as zeros.
+struct tile_pipe {
+  const double* X;
+  long long N, t, step;
+  int D, lane, cur, nbuf;
+  double* buf;
+  // nbuf = 2: the next tile's DMA flies under this tile's arithmetic; 1: half the LDS, more waves per CU (kernels whose
+  // arithmetic, not the stream, sets the pace)
+  __device__ __forceinline__ tile_pipe(const double* X_, long long N_, int D_, double* lds, int lane_, int nbuf_ = 2)
+      : X(X_), N(N_), t(blockIdx.x), step(gridDim.x), D(D_), lane(lane_), cur(0), nbuf(nbuf_), buf(lds) {
+    if (nbuf == 2 && live()) issue(t, buf);
+  }
+  __device__ __forceinline__ bool live() const { return t * TILE < N; }
+  __device__ __forceinline__ int rows() const { return (int)(N - t * TILE < TILE ? N - t * TILE : TILE); }
+  __device__ __forceinline__ void issue(long long tt, double* dst) {
+    if ((tt + 1) * TILE > N) return;
+    const char* src = (const char*)(X + tt * TILE * D);
+    const int n_gran = 32 * D;
+    for (int q = 0; q * 64 < n_gran; ++q) {
+      const int g = q * 64 + lane;
+      if (g < n_gran) __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(src + (long long)g * 16), ZK_LDS_PTR((char*)dst + q * 1024), 16, 0, 2);
     }
   }
-}
+  __device__ __forceinline__ const double* acquire() {
+    double* now = buf + cur * TILE * D;
+    if (nbuf == 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the buffer is no longer read
+      issue(t, now);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile t has landed; the other buffer is no longer read
+    if ((t + 1) * TILE > N) {
+      const long long base = t * TILE * D, total = N * D;
+#pragma unroll 8
+      for (int q = 0; q < D; ++q) {
+        const long long e = base + (long long)q * TILE + lane;
+        now[q * TILE + lane] = e < total ? X[e] : 0.0;
+      }
+      __syncthreads();
+    }
+    const long long nt = t + step;
+    if (nbuf == 2 && nt * TILE < N) issue(nt, buf + (cur ^ 1) * TILE * D);
+    return now;
+  }
+  __device__ __forceinline__ void advance() {
+    t += step;
+    if (nbuf == 2) cur ^= 1;
+  }
+};
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -76,27 +116,23 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---- column statistics: part[block][D] = sum over the block's rows of (x - shift) or (x - shift)^2 ---------------------
-__global__ __launch_bounds__(64) void colsum_kernel(const double* __restrict__ X, long long N, int D, int S,
+__global__ __launch_bounds__(64) void colsum_kernel(const double* __restrict__ X, long long N, int D, int nbuf,
                                                     const double* __restrict__ shift, int square, double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* tile = lds;
   const int lane = threadIdx.x;
-  const long long total = N * D;
   const int j0 = lane, j1 = lane + 64;
   const double m0 = shift && j0 < D ? shift[j0] : 0.0, m1 = shift && j1 < D ? shift[j1] : 0.0;
   double a0 = 0.0, a1 = 0.0;
-  for (long long t = blockIdx.x; t * TILE < N; t += gridDim.x) {
-    __syncthreads();
-    tile_load(X, total, D, S, t * TILE * D, tile, lane);
-    __syncthreads();
-    const int rows = (int)(N - t * TILE < TILE ? N - t * TILE : TILE);
+  for (tile_pipe pipe(X, N, D, lds, lane, nbuf); pipe.live(); pipe.advance()) {
+    const double* tile = pipe.acquire();
+    const int rows = pipe.rows();
     for (int r = 0; r < rows; ++r) {
       if (j0 < D) {
-        const double v = tile[r * S + j0] - m0;
+        const double v = tile[r * D + j0] - m0;
         a0 += square ? v * v : v;
       }
       if (j1 < D) {
-        const double v = tile[r * S + j1] - m1;
+        const double v = tile[r * D + j1] - m1;
         a1 += square ? v * v : v;
       }
     }
@@ -105,36 +141,33 @@ __global__ __launch_bounds__(64) void colsum_kernel(const double* __restrict__ X
   if (j1 < D) part[(long long)blockIdx.x * D + j1] = a1;
 }
 
-// out[i] = sum over blocks (ascending) of part[block][i]
-__global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ part, int n_blocks, int n, double* __restrict__ out) {
+// out[g][i] = sum over the blocks b of group g (b = g * group ... , ascending) of part[b][i]
+__global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ part, int n_blocks, int n, int group,
+                                                     double* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const int b0 = blockIdx.y * group, b1 = b0 + group < n_blocks ? b0 + group : n_blocks;
   double s = 0.0;
-  for (int b = 0; b < n_blocks; ++b) s += part[(long long)b * n + i];
-  out[i] = s;
+  for (int b = b0; b < b1; ++b) s += part[(long long)b * n + i];
+  out[(long long)blockIdx.y * n + i] = s;
 }
 
 // xsq[r] = sum_j (x_rj - mean_j)^2 (row_norms of the centred matrix); count[0] += rows whose norm is not finite
-__global__ __launch_bounds__(64) void rownorm_kernel(const double* __restrict__ X, long long N, int D, int S,
+__global__ __launch_bounds__(64) void rownorm_kernel(const double* __restrict__ X, long long N, int D, int nbuf,
                                                      const double* __restrict__ mean, double* __restrict__ xsq,
                                                      unsigned long long* __restrict__ count) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* tile = lds;
   const int lane = threadIdx.x;
-  const long long total = N * D;
   const ZK_CONST double* cm = zk_const(mean);
   unsigned long long bad = 0;
-  for (long long t = blockIdx.x; t * TILE < N; t += gridDim.x) {
-    __syncthreads();
-    tile_load(X, total, D, S, t * TILE * D, tile, lane);
-    __syncthreads();
-    const double* row = tile + lane * S;
+  for (tile_pipe pipe(X, N, D, lds, lane, nbuf); pipe.live(); pipe.advance()) {
+    const double* row = pipe.acquire() + lane * D;
     double s = 0.0;
     for (int i = 0; i < D; ++i) {
       const double v = row[i] - cm[i];
       s = __builtin_fma(v, v, s);
     }
-    const long long r = t * TILE + lane;
+    const long long r = pipe.t * TILE + lane;
     if (r < N) {
       xsq[r] = s;
       bad += !(s <= 1.7976931348623157e308);
@@ -144,17 +177,17 @@ __global__ __launch_bounds__(64) void rownorm_kernel(const double* __restrict__ 
   if (any && bad) atomicAdd(count, bad);
 }
 
-// dots of the centred row with four wave-uniform vectors: Ct is [D][KP] (vector index fastest)
-__device__ __forceinline__ void dots4(const double* __restrict__ row, int D, const ZK_CONST double* cm, const ZK_CONST double* ct,
-                                      int KP, double& d0, double& d1, double& d2, double& d3) {
-  d0 = d1 = d2 = d3 = 0.0;
+// dots of the centred row with KC wave-uniform vectors: ct is [D][KP] (vector index fastest)
+template <int KC>
+__device__ __forceinline__ void dots(const double* __restrict__ row, int D, const ZK_CONST double* cm, const ZK_CONST double* ct,
+                                     int KP, double (&d)[KC]) {
+#pragma unroll
+  for (int c = 0; c < KC; ++c) d[c] = 0.0;
   for (int i = 0; i < D; ++i) {
     const double v = row[i] - cm[i];
     const ZK_CONST double* c = ct + (long long)i * KP;
-    d0 = __builtin_fma(v, c[0], d0);
-    d1 = __builtin_fma(v, c[1], d1);
-    d2 = __builtin_fma(v, c[2], d2);
-    d3 = __builtin_fma(v, c[3], d3);
+#pragma unroll
+    for (int cc = 0; cc < KC; ++cc) d[cc] = __builtin_fma(v, c[cc], d[cc]);
   }
 }
 
@@ -162,43 +195,35 @@ __device__ __forceinline__ void dots4(const double* __restrict__ row, int D, con
 // candidate rows, d = max(0, (-2 x.c + |c|^2) + |x|^2) as sklearn's _euclidean_distances builds them, folded with the
 // closest distance so far; out[c][r]; part[block][c] = potential of candidate c over the block's rows ----------------
 template <int TP>
-__global__ __launch_bounds__(64) void seed_kernel(const double* __restrict__ X, long long N, int D, int S,
+__global__ __launch_bounds__(64) void seed_kernel(const double* __restrict__ X, long long N, int D, int nbuf,
                                                   const double* __restrict__ mean, const double* __restrict__ Ct,
                                                   const double* __restrict__ cc, int t, const double* __restrict__ xsq,
                                                   const double* __restrict__ closest, double* __restrict__ out,
                                                   double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* tile = lds;
   const int lane = threadIdx.x;
-  const long long total = N * D;
   const ZK_CONST double* cm = zk_const(mean);
   const ZK_CONST double* ct = zk_const(Ct);
   const ZK_CONST double* ccc = zk_const(cc);
   double pot[TP];
 #pragma unroll
   for (int c = 0; c < TP; ++c) pot[c] = 0.0;
-  for (long long tl = blockIdx.x; tl * TILE < N; tl += gridDim.x) {
-    __syncthreads();
-    tile_load(X, total, D, S, tl * TILE * D, tile, lane);
-    __syncthreads();
-    const double* row = tile + lane * S;
-    const long long r = tl * TILE + lane;
+  for (tile_pipe pipe(X, N, D, lds, lane, nbuf); pipe.live(); pipe.advance()) {
+    const double* row = pipe.acquire() + lane * D;
+    const long long r = pipe.t * TILE + lane;
     const bool live = r < N;
     const double xs = live ? xsq[r] : 0.0;
     const double prev = closest && live ? closest[r] : std::numeric_limits<double>::infinity();
+    double d[TP];
+    dots<TP>(row, D, cm, ct, TP, d);
 #pragma unroll
-    for (int c0 = 0; c0 < TP; c0 += 4) {
-      double d[4];
-      dots4(row, D, cm, ct + c0, TP, d[0], d[1], d[2], d[3]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        double v = __builtin_fma(-2.0, d[c], ccc[c0 + c]) + xs;
-        v = v > 0.0 ? v : 0.0;
-        v = v < prev ? v : prev;
-        if (live && c0 + c < t) {
-          out[(long long)(c0 + c) * N + r] = v;
-          pot[c0 + c] += v;
-        }
+    for (int c = 0; c < TP; ++c) {
+      double v = __builtin_fma(-2.0, d[c], ccc[c]) + xs;
+      v = v > 0.0 ? v : 0.0;
+      v = v < prev ? v : prev;
+      if (live && c < t) {
+        __builtin_nontemporal_store(v, out + (long long)c * N + r);
+        pot[c] += v;
       }
     }
   }
@@ -227,88 +252,139 @@ __global__ __launch_bounds__(256) void blocksum_kernel(const double* __restrict_
 
 // ---- one Lloyd iteration (sklearn _k_means_lloyd.pyx lloyd_iter_chunked_dense): label = first argmin_c (|c|^2 - 2 x.c);
 // with `update`: part[block][c][0..D-1] = sum of the centred rows of cluster c, [D] = their number -----------------------
-__global__ __launch_bounds__(64) void lloyd_kernel(const double* __restrict__ X, long long N, int D, int S,
+template <int KC>
+__device__ __forceinline__ void lloyd_chunk(const double* __restrict__ row, int D, const ZK_CONST double* cm, const ZK_CONST double* ct,
+                                            const ZK_CONST double* cs, int KP, int c0, double& best, int& bl) {
+  double d[KC];
+  dots<KC>(row, D, cm, ct + c0, KP, d);
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const double sc = __builtin_fma(-2.0, d[c], cs[c0 + c]);
+    if (sc < best) best = sc, bl = c0 + c;
+  }
+}
+
+// sum over the rows in `mask` (wave-uniform) of column j of the tile, centred by mj; j == D: their number.  Four rows per
+// step: four scalar bit extractions and LDS reads, one wait, then the adds in row order.
+__device__ __forceinline__ double masked_column_sum(const double* __restrict__ tile, int D, int j, double mj, unsigned long long mask) {
+  const double* col = tile + (j < D ? j : D - 1);
+  const int n_rows = __builtin_popcountll(mask);
+  int n = n_rows;
+  double acc = 0.0;
+  auto next = [&]() {
+    const int r = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    return col[r * D];
+  };
+  for (; n >= 4; n -= 4) {
+    const double v0 = next(), v1 = next(), v2 = next(), v3 = next();
+    acc += v0 - mj;
+    acc += v1 - mj;
+    acc += v2 - mj;
+    acc += v3 - mj;
+  }
+  for (; n > 0; --n) acc += next() - mj;
+  return j == D ? (double)n_rows : acc;
+}
+
+// KMAX > 0: k <= KMAX, the per-cluster column sums live in registers (lane = column; the rows of cluster c are the set bits
+// of ballot(label == c), walked by a scalar loop); KMAX = 0: any k, LDS floating-point adds into a wave-private table
+// (an LDS f64 atomic costs ~280 cycles per wave: 2.4x the whole pass at k = 6, so only where the registers do not reach).
+template <int KMAX>
+__global__ __launch_bounds__(64) void lloyd_kernel(const double* __restrict__ X, long long N, int D, int nbuf,
                                                    const double* __restrict__ mean, const double* __restrict__ Ct,
                                                    const double* __restrict__ csq, int KP, int k, int32_t* __restrict__ labels,
                                                    int update, double* __restrict__ part, unsigned long long* __restrict__ changed) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* tile = lds;
-  double* sums = tile + TILE * S;
+  double* sums = lds + nbuf * TILE * D;
   const int D1 = D + 1;
-  int* lab = (int*)(sums + (update ? k * D1 : 0));
   const int lane = threadIdx.x;
-  const long long total = N * D;
   const ZK_CONST double* cm = zk_const(mean);
   const ZK_CONST double* ct = zk_const(Ct);
   const ZK_CONST double* cs = zk_const(csq);
-  if (update)
+  if (KMAX == 0 && update)
     for (int e = lane; e < k * D1; e += 64) sums[e] = 0.0;
   const int j0 = lane, j1 = lane + 64;
   const double m0 = j0 < D ? mean[j0] : 0.0, m1 = j1 < D ? mean[j1] : 0.0;
+  constexpr int KA = KMAX > 0 ? KMAX : 1;
+  double acc0[KA], acc1[KA];
+#pragma unroll
+  for (int c = 0; c < KA; ++c) acc0[c] = acc1[c] = 0.0;
   unsigned long long nchg = 0;
-  for (long long tl = blockIdx.x; tl * TILE < N; tl += gridDim.x) {
-    __syncthreads();
-    tile_load(X, total, D, S, tl * TILE * D, tile, lane);
-    __syncthreads();
-    const double* row = tile + lane * S;
+  for (tile_pipe pipe(X, N, D, lds, lane, nbuf); pipe.live(); pipe.advance()) {
+    const double* tile = pipe.acquire();
+    const double* row = tile + lane * D;
     double best = std::numeric_limits<double>::infinity();
     int bl = 0;
-    for (int c0 = 0; c0 < KP; c0 += 4) {
-      double d0, d1, d2, d3;
-      dots4(row, D, cm, ct + c0, KP, d0, d1, d2, d3);
-      const double s0 = __builtin_fma(-2.0, d0, cs[c0]), s1 = __builtin_fma(-2.0, d1, cs[c0 + 1]),
-                   s2 = __builtin_fma(-2.0, d2, cs[c0 + 2]), s3 = __builtin_fma(-2.0, d3, cs[c0 + 3]);
-      if (s0 < best) best = s0, bl = c0;
-      if (s1 < best) best = s1, bl = c0 + 1;
-      if (s2 < best) best = s2, bl = c0 + 2;
-      if (s3 < best) best = s3, bl = c0 + 3;
-    }
-    const long long r = tl * TILE + lane;
+    int c0 = 0;
+    for (; c0 + 8 <= KP; c0 += 8) lloyd_chunk<8>(row, D, cm, ct, cs, KP, c0, best, bl);
+    if (c0 < KP) lloyd_chunk<4>(row, D, cm, ct, cs, KP, c0, best, bl);
+    const long long r = pipe.t * TILE + lane;
     const bool live = r < N;
     if (live) {
       nchg += labels[r] != bl;
       labels[r] = bl;
     }
     if (update) {
-      lab[lane] = live ? bl : -1;
-      __syncthreads();
-      const int rows = (int)(N - tl * TILE < TILE ? N - tl * TILE : TILE);
-      for (int rr = 0; rr < rows; ++rr) {
-        const int l = __builtin_amdgcn_readfirstlane(lab[rr]);
-        double* dst = sums + l * D1;
-        if (j0 <= D) {
-          const double v = j0 < D ? tile[rr * S + j0] - m0 : 1.0;
-          (void)__hip_atomic_fetch_add(dst + j0, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const int rows = pipe.rows();
+      if constexpr (KMAX > 0) {
+        const unsigned long long valid = rows == TILE ? ~0ull : (1ull << rows) - 1;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) {
+          const unsigned long long mask = __ballot(bl == c) & valid;
+          if (j0 <= D) acc0[c] += masked_column_sum(tile, D, j0, m0, mask);
+          if (D >= 64 && j1 <= D) acc1[c] += masked_column_sum(tile, D, j1, m1, mask);
         }
-        if (j1 <= D) {
-          const double v = j1 < D ? tile[rr * S + j1] - m1 : 1.0;
-          (void)__hip_atomic_fetch_add(dst + j1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      } else {
+        // lane = column; the label of row rr is lane rr's `bl`.  Eight rows per step: their reads first, then the adds
+        for (int r0 = 0; r0 < rows; r0 += 8) {
+          double v0[8], v1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            v0[u] = j0 < D ? tile[(r0 + u) * D + j0] : m0 + 1.0;
+            v1[u] = j1 < D ? tile[(r0 + u) * D + j1] : m1 + 1.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (r0 + u < rows) {
+              const int l = __builtin_amdgcn_readlane(bl, r0 + u);
+              double* dst = sums + l * D1;
+              if (j0 <= D) (void)__hip_atomic_fetch_add(dst + j0, v0[u] - m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              if (j1 <= D) (void)__hip_atomic_fetch_add(dst + j1, v1[u] - m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+          }
         }
       }
     }
   }
   __syncthreads();
-  if (update)
-    for (int e = lane; e < k * D1; e += 64) part[(long long)blockIdx.x * k * D1 + e] = sums[e];
+  if (update) {
+    double* out = part + (long long)blockIdx.x * k * D1;
+    if constexpr (KMAX > 0) {
+#pragma unroll
+      for (int c = 0; c < KMAX; ++c)
+        if (c < k) {
+          if (j0 <= D) out[c * D1 + j0] = acc0[c];
+          if (j1 <= D) out[c * D1 + j1] = acc1[c];
+        }
+    } else {
+      for (int e = lane; e < k * D1; e += 64) out[e] = sums[e];
+    }
+  }
   if (__ballot(nchg != 0) && nchg) atomicAdd(changed, nchg);
 }
 
 // dist[r] = sum_j ((x_rj - mean_j) - centre[label_r][j])^2  (sklearn _relocate_empty_clusters_dense)
-__global__ __launch_bounds__(64) void owndist_kernel(const double* __restrict__ X, long long N, int D, int S,
+__global__ __launch_bounds__(64) void owndist_kernel(const double* __restrict__ X, long long N, int D, int nbuf,
                                                      const double* __restrict__ mean, const double* __restrict__ centers,
                                                      const int32_t* __restrict__ labels, double* __restrict__ dist) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* tile = lds;
   const int lane = threadIdx.x;
-  const long long total = N * D;
   const ZK_CONST double* cm = zk_const(mean);
-  for (long long tl = blockIdx.x; tl * TILE < N; tl += gridDim.x) {
-    __syncthreads();
-    tile_load(X, total, D, S, tl * TILE * D, tile, lane);
-    __syncthreads();
-    const long long r = tl * TILE + lane;
+  for (tile_pipe pipe(X, N, D, lds, lane, nbuf); pipe.live(); pipe.advance()) {
+    const double* row = pipe.acquire() + lane * D;
+    const long long r = pipe.t * TILE + lane;
     if (r < N) {
-      const double* row = tile + lane * S;
       const double* c = centers + (long long)labels[r] * D;
       double s = 0.0;
       for (int i = 0; i < D; ++i) {
@@ -322,44 +398,70 @@ __global__ __launch_bounds__(64) void owndist_kernel(const double* __restrict__ 
 
 // ---- Gaussian mixture E step (sklearn/mixture/_gaussian_mixture.py _estimate_log_gaussian_prob + _base.py
 // _estimate_log_prob_resp): per component y = x P - mu P with P the upper-triangular Cholesky factor of the precision
-// ([k][D][DP] row-major, DP = D rounded up to 8, zeros below the diagonal and in the padding; b = mu P as [k][DP]),
+// ([k][D][DP] row-major, DP = D rounded up to ZK_EW, zeros below the diagonal and in the padding; b = mu P as [k][DP]),
 // lp_c = (-0.5 (D log 2pi + |y|^2) + logdet_c) + logw_c; log-sum-exp over components; resp (k, N) = exp(lp - lse);
 // label = first argmax; part[block] = sum of lse over the block's rows -----------------------------------------------------
-__global__ __launch_bounds__(64) void estep_kernel(const double* __restrict__ X, long long N, int D, int S, int DP,
+#ifndef ZK_EW
+#define ZK_EW 16  // columns of y per pass of the E step (8: 4.2 ms, 16: 2.9 ms per 4 M x 45 rows at k = 6)
+#endif
+#define ZK_LGKM_WAIT()                \
+  __builtin_amdgcn_s_waitcnt(0xC07F); \
+  __builtin_amdgcn_sched_barrier(0)
+
+__global__ __launch_bounds__(64) void estep_kernel(const double* __restrict__ X, long long N, int D, int DP, int nbuf,
                                                    const double* __restrict__ P, const double* __restrict__ B,
                                                    const double* __restrict__ cst /* [k][2]: logdet, logw */, double dlog2pi, int k,
                                                    double* __restrict__ resp, int32_t* __restrict__ labels,
                                                    double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* tile = lds;
-  double* lp = tile + TILE * S;  // [k][64]
+  double* lp = lds + nbuf * TILE * D;  // [k][64]
   const int lane = threadIdx.x;
-  const long long total = N * D;
   double lse_sum = 0.0;
-  for (long long tl = blockIdx.x; tl * TILE < N; tl += gridDim.x) {
-    __syncthreads();
-    tile_load(X, total, D, S, tl * TILE * D, tile, lane);
-    __syncthreads();
-    const double* row = tile + lane * S;
+  for (tile_pipe pipe(X, N, D, lds, lane, nbuf); pipe.live(); pipe.advance()) {
+    const double* row = pipe.acquire() + lane * D;
     double best = -std::numeric_limits<double>::infinity();
     int bl = 0;
     for (int c = 0; c < k; ++c) {
       const ZK_CONST double* pc = zk_const(P) + (long long)c * D * DP;
       const ZK_CONST double* bc = zk_const(B) + (long long)c * DP;
       double sq = 0.0;
-      for (int j0 = 0; j0 < DP; j0 += 8) {
-        double a[8];
+      // ZK_EW columns of y at a time; row i of the factor (ZK_EW wave-uniform doubles) and x_i are requested one step ahead of
+      // their FMAs (the scalar-operand pipelining of zk_sep.h: wait for this step's operands, request the next, compute).
+      // The prefetch past the last row reads the next component's first row / the table that follows: in bounds.
+      for (int j0 = 0; j0 < DP; j0 += ZK_EW) {
+        double a[ZK_EW], Pn[ZK_EW];
+        const ZK_CONST double* pr = pc + j0;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) a[jj] = -bc[j0 + jj];
-        const int imax = j0 + 8 < D ? j0 + 8 : D;
-        for (int i = 0; i < imax; ++i) {
-          const double x = row[i];
-          const ZK_CONST double* pr = pc + (long long)i * DP + j0;
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) a[jj] = __builtin_fma(x, pr[jj], a[jj]);
+        for (int jj = 0; jj < ZK_EW; ++jj) a[jj] = -bc[j0 + jj], Pn[jj] = pr[jj];
+        double xn = row[0];
+        const int imax = j0 + ZK_EW < D ? j0 + ZK_EW : D;
+#define ZK_ESTEP(NEXT)                                                                    \
+  {                                                                                       \
+    ZK_LGKM_WAIT();                                                                       \
+    const double x = xn;                                                                  \
+    double Pc[ZK_EW];                                                                     \
+    _Pragma("unroll") for (int jj = 0; jj < ZK_EW; ++jj) Pc[jj] = Pn[jj];                 \
+    xn = row[i + (NEXT)];                                                                 \
+    _Pragma("unroll") for (int jj = 0; jj < ZK_EW; ++jj) Pn[jj] = pr[(NEXT)*DP + jj];     \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    _Pragma("unroll") for (int jj = 0; jj < ZK_EW; ++jj) a[jj] = __builtin_fma(x, Pc[jj], a[jj]); \
+  }
+        int i = 0;
+        for (; i + 3 < imax; i += 4) {
+          ZK_ESTEP(1)
+          ZK_ESTEP(2)
+          ZK_ESTEP(3)
+          ZK_ESTEP(4)
+          pr += 4 * DP;
         }
+        for (; i < imax; ++i) {
+          ZK_ESTEP(1)
+          pr += DP;
+        }
+#undef ZK_ESTEP
+        ZK_LGKM_WAIT();
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) sq = __builtin_fma(a[jj], a[jj], sq);
+        for (int jj = 0; jj < ZK_EW; ++jj) sq = __builtin_fma(a[jj], a[jj], sq);
       }
       const ZK_CONST double* cc = zk_const(cst) + 2 * c;
       const double v = (-0.5 * (dlog2pi + sq) + cc[0]) + cc[1];
@@ -369,12 +471,12 @@ __global__ __launch_bounds__(64) void estep_kernel(const double* __restrict__ X,
     double s = 0.0;
     for (int c = 0; c < k; ++c) s += exp(lp[c * 64 + lane] - best);
     const double lse = log(s) + best;
-    const long long r = tl * TILE + lane;
+    const long long r = pipe.t * TILE + lane;
     if (r < N) {
       lse_sum += lse;
       if (labels) labels[r] = bl;
       if (resp)
-        for (int c = 0; c < k; ++c) resp[(long long)c * N + r] = exp(lp[c * 64 + lane] - lse);
+        for (int c = 0; c < k; ++c) __builtin_nontemporal_store(exp(lp[c * 64 + lane] - lse), resp + (long long)c * N + r);
     }
   }
   const double tot = wave_sum(lse_sum);
@@ -389,34 +491,59 @@ __global__ __launch_bounds__(256) void onehot_kernel(const int32_t* __restrict__
   for (int c = 0; c < k; ++c) resp[(long long)c * N + r] = l == c ? 1.0 : 0.0;
 }
 
-// part[block] = sum_r w_r [x_r - shift | 1]^T [x_r - shift | 1]  (D+1 x D+1, upper triangle of 4 x 4 register tiles; see
-// gram_kernel of zk_consumers.hip), w = one plane of the responsibilities
-__global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ X, long long N, int D, int T,
+// part[block][group] = sum over the group's rows of w_r [x_r - shift | 1]^T [x_r - shift | 1]  (D+1 x D+1; upper triangle
+// written, mirrored), w = one plane of the responsibilities.  The (4T x 4T)-padded matrix is cut into 4 x 4 register
+// tiles; only the T (T + 1) / 2 tiles of the upper triangle are computed, one per thread, and the threads of a workgroup
+// form G groups of that many that share the LDS-staged 64-row tile and take every G-th row of it.
+__global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ X, long long N, int D, int T, int G,
                                                      const double* __restrict__ shift, const double* __restrict__ w,
                                                      double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double tile[];  // [64][4T] then [64] weights
-  const int P = 4 * T;
+  const int P = 4 * T, n_ut = T * (T + 1) / 2;
   double* wt = tile + 64 * P;
-  const int ti = threadIdx.x / T, tj = threadIdx.x % T;
-  const int nthreads = T * T;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int g = tid / n_ut, u = tid - g * n_ut;
+  const bool worker = g < G;
+  int ti = 0, rem = u;
+  while (rem >= T - ti) rem -= T - ti, ++ti;
+  const int tj = ti + rem;
   double acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  // columns D .. P-1 never change: the constant 1, then zero padding
+  for (int e = tid; e < 64 * (P - D); e += nthreads) {
+    const int r = e / (P - D), c = D + e - r * (P - D);
+    tile[r * P + c] = c == D ? 1.0 : 0.0;
+  }
+  const long long total = N * D;
+  const int adv_r = nthreads / D, adv_c = nthreads - adv_r * D;
   for (long long r0 = (long long)blockIdx.x * 64; r0 < N; r0 += (long long)gridDim.x * 64) {
     __syncthreads();
-    for (int e = threadIdx.x; e < 64 * P; e += nthreads) {
-      const int r = e / P, c = e - r * P;
-      double v = 0.0;
-      if (r0 + r < N) v = c < D ? X[(r0 + r) * D + c] - shift[c] : (c == D ? 1.0 : 0.0);
-      tile[e] = v;
+    {  // the tile's 64 * D contiguous doubles, eight coalesced loads in flight per thread
+      int r = tid / D, c = tid - r * D;
+      const long long base = r0 * D;
+      for (int e0 = tid; e0 < 64 * D; e0 += 8 * nthreads) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int e = e0 + q * nthreads;
+          v[q] = e < 64 * D && base + e < total ? __builtin_nontemporal_load(X + base + e) : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (e0 + q * nthreads < 64 * D) tile[r * P + c] = v[q] - shift[c];
+          r += adv_r, c += adv_c;
+          if (c >= D) c -= D, ++r;
+        }
+      }
     }
-    for (int r = threadIdx.x; r < 64; r += nthreads) wt[r] = r0 + r < N ? w[r0 + r] : 0.0;
+    for (int r = tid; r < 64; r += nthreads) wt[r] = r0 + r < N ? w[r0 + r] : 0.0;
     __syncthreads();
-    if (ti <= tj) {
-#pragma unroll 4
-      for (int r = 0; r < 64; ++r) {
+    if (worker) {
+#pragma unroll 2
+      for (int r = g; r < 64; r += G) {
         const double* row = tile + r * P;
         const double wr = wt[r];
         double xi[4], xj[4];
@@ -429,9 +556,9 @@ __global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ 
       }
     }
   }
-  const int D1 = D + 1;
-  double* out = part + (long long)blockIdx.x * D1 * D1;
-  if (ti <= tj) {
+  if (worker) {
+    const int D1 = D + 1;
+    double* out = part + ((long long)blockIdx.x * G + g) * D1 * D1;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -446,7 +573,9 @@ __global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ 
 }
 
 // ---- host helpers ------------------------------------------------------------------------------------------------
-size_t tile_lds(const zk_rows* m) { return (size_t)TILE * m->S * sizeof(double); }
+// two tile buffers (the next tile's DMA under this tile's arithmetic) while three waves still fit a CU's 160 KiB, else one
+int tile_bufs(const zk_rows* m, size_t extra = 0) { return 3 * ((size_t)2 * TILE * m->D * sizeof(double) + extra + 512) <= 160 * 1024 ? 2 : 1; }
+size_t tile_lds(const zk_rows* m, int nbuf) { return (size_t)nbuf * TILE * m->D * sizeof(double); }
 
 // persistent single-wave workgroups: as many per CU as the LDS tile allows (at most 8), never more than tiles
 int row_grid(const zk_rows* m, size_t lds_bytes) {
@@ -467,13 +596,24 @@ int upload_tab(zk_rows* m, const std::vector<double>& h) {
   return 0;
 }
 
+// fixed-order sum of the per-workgroup partial results ([n_blocks][n] in d_part) -> host; two levels (groups of 32 blocks,
+// then the groups) so that thousands of partials do not become one thread's serial loop
 int reduce_to_host(zk_rows* m, int n_blocks, int n, double* host_out) {
-  int rc = ensure(&m->d_red, &m->red_bytes, (size_t)n * sizeof(double));
+  const int group = 32, n_groups = (n_blocks + group - 1) / group;
+  int rc = ensure(&m->d_red, &m->red_bytes, (size_t)(n_groups + 1) * n * sizeof(double));
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, (const double*)m->d_part, n_blocks, n,
-                     (double*)m->d_red);
+  double* fin = (double*)m->d_red;
+  double* mid = fin + n;
+  if (n_groups > 1) {
+    hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256, n_groups), dim3(256), 0, m->stream, (const double*)m->d_part, n_blocks, n,
+                       group, mid);
+    hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, m->stream, (const double*)mid, n_groups, n, n_groups, fin);
+  } else {
+    hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, m->stream, (const double*)m->d_part, n_blocks, n, n_blocks,
+                       fin);
+  }
   ZK_HIP(hipGetLastError());
-  ZK_HIP(hipMemcpyAsync(host_out, m->d_red, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  ZK_HIP(hipMemcpyAsync(host_out, fin, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
   ZK_HIP(hipStreamSynchronize(m->stream));
   return 0;
 }
@@ -522,7 +662,6 @@ static int rows_new(int device, const double* X_dev, int64_t N, int D, bool own,
   m->device = device;
   m->N = N;
   m->D = D;
-  m->S = D | 1;
   m->X = X_dev;
   m->own = own;
   const int rc = rows_init(m);
@@ -572,27 +711,28 @@ extern "C" const double* zk_rows_data(const zk_rows* m) { return m ? m->X : null
 extern "C" int zk_rows_center(zk_rows* m, double* mean_out, double* var_out, int64_t* n_bad_out) {
   if (!m || !mean_out || !var_out || !n_bad_out) return zk_fail(ZK_E_BADARG, "null pointer");
   ZK_ON_DEVICE(m->device);
-  const size_t lds = tile_lds(m);
+  const int nbuf = tile_bufs(m);
+  const size_t lds = tile_lds(m, nbuf);
   int rc = check_lds(lds);
   if (rc) return rc;
   if ((rc = allow_lds(colsum_kernel, lds)) || (rc = allow_lds(rownorm_kernel, lds))) return rc;
   const int grid = row_grid(m, lds);
   if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * m->D * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)nullptr, 0,
+  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, nbuf, (const double*)nullptr, 0,
                      (double*)m->d_part);
   ZK_HIP(hipGetLastError());
   if ((rc = reduce_to_host(m, grid, m->D, mean_out))) return rc;
   for (int j = 0; j < m->D; ++j) mean_out[j] /= (double)m->N;
   ZK_HIP(hipMemcpyAsync(m->d_mean, mean_out, (size_t)m->D * sizeof(double), hipMemcpyHostToDevice, m->stream));
   ZK_HIP(hipStreamSynchronize(m->stream));
-  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)m->d_mean, 1,
+  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, nbuf, (const double*)m->d_mean, 1,
                      (double*)m->d_part);
   ZK_HIP(hipGetLastError());
   if ((rc = reduce_to_host(m, grid, m->D, var_out))) return rc;
   for (int j = 0; j < m->D; ++j) var_out[j] /= (double)m->N;
   if (!m->d_xsq) ZK_HIP(hipMalloc((void**)&m->d_xsq, (size_t)m->N * sizeof(double)));
   ZK_HIP(hipMemsetAsync(m->d_count, 0, sizeof(unsigned long long), m->stream));
-  hipLaunchKernelGGL(rownorm_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)m->d_mean,
+  hipLaunchKernelGGL(rownorm_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, nbuf, (const double*)m->d_mean,
                      m->d_xsq, m->d_count);
   ZK_HIP(hipGetLastError());
   unsigned long long bad = 0;
@@ -654,7 +794,8 @@ extern "C" int zk_kmeans_seed_step(zk_rows* m, const double* cand, const double*
   for (int c = 0; c < t; ++c) m->h_buf[(size_t)m->D * TP + c] = cand_sq[c];
   int rc = upload_tab(m, m->h_buf);
   if (rc) return rc;
-  const size_t lds = tile_lds(m);
+  const int nbuf = tile_bufs(m);
+  const size_t lds = tile_lds(m, nbuf);
   if ((rc = check_lds(lds))) return rc;
   const int grid = row_grid(m, lds);
   const int dst = use_closest ? 1 - m->seed_cur : m->seed_cur;
@@ -664,11 +805,11 @@ extern "C" int zk_kmeans_seed_step(zk_rows* m, const double* cand, const double*
   const double* closest = use_closest ? m->d_closest : nullptr;
   if (TP == 4) {
     if ((rc = allow_lds(seed_kernel<4>, lds))) return rc;
-    hipLaunchKernelGGL(seed_kernel<4>, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)m->d_mean,
+    hipLaunchKernelGGL(seed_kernel<4>, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, nbuf, (const double*)m->d_mean,
                        tab, tab + (size_t)m->D * TP, t, (const double*)m->d_xsq, closest, (double*)m->d_seed[dst], (double*)m->d_part);
   } else {
     if ((rc = allow_lds(seed_kernel<8>, lds))) return rc;
-    hipLaunchKernelGGL(seed_kernel<8>, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)m->d_mean,
+    hipLaunchKernelGGL(seed_kernel<8>, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, nbuf, (const double*)m->d_mean,
                        tab, tab + (size_t)m->D * TP, t, (const double*)m->d_xsq, closest, (double*)m->d_seed[dst], (double*)m->d_part);
   }
   ZK_HIP(hipGetLastError());
@@ -733,8 +874,11 @@ extern "C" int zk_kmeans_step(zk_rows* m, const double* centers, int k, int upda
   int rc = upload_tab(m, m->h_buf);
   m->h_buf.clear();
   if (rc) return rc;
-  const size_t lds = tile_lds(m) + (update ? (size_t)k * D1 * sizeof(double) : 0) + 64 * sizeof(int);
-  if ((rc = check_lds(lds)) || (rc = allow_lds(lloyd_kernel, lds))) return rc;
+  const int kmax = k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : 0;  // per-cluster sums in registers up to 16 clusters
+  const size_t sums_lds = update && !kmax ? (size_t)k * D1 * sizeof(double) : 0;
+  const int nbuf = tile_bufs(m, sums_lds);
+  const size_t lds = tile_lds(m, nbuf) + sums_lds;
+  if ((rc = check_lds(lds))) return rc;
   const int grid = row_grid(m, lds);
   if (!m->d_labels) {
     ZK_HIP(hipMalloc((void**)&m->d_labels, (size_t)m->N * sizeof(int32_t)));
@@ -743,8 +887,20 @@ extern "C" int zk_kmeans_step(zk_rows* m, const double* centers, int k, int upda
   if (update && (rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * k * D1 * sizeof(double)))) return rc;
   ZK_HIP(hipMemsetAsync(m->d_count, 0, sizeof(unsigned long long), m->stream));
   const double* tab = (const double*)m->d_tab;
-  hipLaunchKernelGGL(lloyd_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S, (const double*)m->d_mean, tab,
-                     tab + (size_t)m->D * KP, KP, k, m->d_labels, update, (double*)m->d_part, m->d_count);
+#define ZK_LLOYD(KM)                                                                                                              \
+  {                                                                                                                               \
+    if ((rc = allow_lds(lloyd_kernel<KM>, lds))) return rc;                                                                       \
+    hipLaunchKernelGGL(lloyd_kernel<KM>, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, nbuf,                 \
+                       (const double*)m->d_mean, tab, tab + (size_t)m->D * KP, KP, k, m->d_labels, update, (double*)m->d_part,    \
+                       m->d_count);                                                                                               \
+  }
+  switch (kmax) {
+    case 4: ZK_LLOYD(4) break;
+    case 8: ZK_LLOYD(8) break;
+    case 16: ZK_LLOYD(16) break;
+    default: ZK_LLOYD(0) break;
+  }
+#undef ZK_LLOYD
   ZK_HIP(hipGetLastError());
   unsigned long long chg = 0;
   if (update) {
@@ -791,11 +947,12 @@ extern "C" int zk_kmeans_own_distance(zk_rows* m, const double* centers, int k, 
   int rc = upload_tab(m, m->h_buf);
   m->h_buf.clear();
   if (rc) return rc;
-  const size_t lds = tile_lds(m);
+  const int nbuf = tile_bufs(m);
+  const size_t lds = tile_lds(m, nbuf);
   if ((rc = check_lds(lds)) || (rc = allow_lds(owndist_kernel, lds))) return rc;
   const int dst = 1 - m->seed_cur;  // the seeding scratch is free by now
   if ((rc = ensure(&m->d_seed[dst], &m->seed_bytes[dst], (size_t)m->N * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(owndist_kernel, dim3(row_grid(m, lds)), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, m->S,
+  hipLaunchKernelGGL(owndist_kernel, dim3(row_grid(m, lds)), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, nbuf,
                      (const double*)m->d_mean, (const double*)m->d_tab, (const int32_t*)m->d_labels, (double*)m->d_seed[dst]);
   ZK_HIP(hipGetLastError());
   ZK_HIP(hipMemcpyAsync(dist_host, m->d_seed[dst], (size_t)m->N * sizeof(double), hipMemcpyDeviceToHost, m->stream));
@@ -814,7 +971,7 @@ extern "C" int zk_gmm_estep(zk_rows* m, const double* prec_chol, const double* m
   if (!m || !prec_chol || !means || !log_det || !log_w || !lse_sum_out) return zk_fail(ZK_E_BADARG, "null pointer");
   if (k < 1 || k > 64) return zk_fail(ZK_E_BADARG, "1 to 64 mixture components");
   ZK_ON_DEVICE(m->device);
-  const int D = m->D, DP = (D + 7) & ~7;
+  const int D = m->D, DP = (D + ZK_EW - 1) / ZK_EW * ZK_EW;
   std::vector<double>& h = m->h_buf;
   h.assign((size_t)k * D * DP + (size_t)k * DP + 2 * (size_t)k, 0.0);
   double* P = h.data();
@@ -835,14 +992,16 @@ extern "C" int zk_gmm_estep(zk_rows* m, const double* prec_chol, const double* m
   int rc = upload_tab(m, h);
   h.clear();
   if (rc) return rc;
-  const size_t lds = tile_lds(m) + (size_t)k * 64 * sizeof(double);
+  static const int nbuf_env = getenv("ZK_ESTEP_NBUF") ? atoi(getenv("ZK_ESTEP_NBUF")) : 1;
+  const int nbuf = nbuf_env == 2 ? 2 : 1;  // the arithmetic sets the pace: one buffer, twice the waves per CU
+  const size_t lds = tile_lds(m, nbuf) + (size_t)k * 64 * sizeof(double);
   if ((rc = check_lds(lds)) || (rc = allow_lds(estep_kernel, lds))) return rc;
   const int grid = row_grid(m, lds);
   if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * sizeof(double)))) return rc;
   if (want_resp && (rc = ensure(&m->d_resp, &m->resp_bytes, (size_t)k * m->N * sizeof(double)))) return rc;
   if (!m->d_labels) ZK_HIP(hipMalloc((void**)&m->d_labels, (size_t)m->N * sizeof(int32_t)));
   const double* tab = (const double*)m->d_tab;
-  hipLaunchKernelGGL(estep_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, D, m->S, DP, tab, tab + (size_t)k * D * DP,
+  hipLaunchKernelGGL(estep_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, D, DP, nbuf, tab, tab + (size_t)k * D * DP,
                      tab + (size_t)k * D * DP + (size_t)k * DP, (double)D * std::log(2.0 * M_PI), k,
                      want_resp ? (double*)m->d_resp : nullptr, m->d_labels, (double*)m->d_part);
   ZK_HIP(hipGetLastError());
@@ -868,18 +1027,22 @@ extern "C" int zk_gmm_moments(zk_rows* m, int c, const double* shift, double* gr
   if (!m || !shift || !gram_out) return zk_fail(ZK_E_BADARG, "null pointer");
   if (!m->d_resp || c < 0 || (size_t)(c + 1) * m->N * sizeof(double) > m->resp_bytes) return zk_fail(ZK_E_BADARG, "no such component");
   ZK_ON_DEVICE(m->device);
-  const int D = m->D, D1 = D + 1, T = (D1 + 3) / 4;
+  const int D = m->D, D1 = D + 1, T = (D1 + 3) / 4, n_ut = T * (T + 1) / 2;
   m->h_buf.assign(shift, shift + D);
   int rc = upload_tab(m, m->h_buf);
   m->h_buf.clear();
   if (rc) return rc;
-  long long blocks = (m->N + 63) / 64;
-  if (blocks > 2LL * m->n_cu) blocks = 2LL * m->n_cu;
-  if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)blocks * D1 * D1 * sizeof(double)))) return rc;
+  const int threads = std::max(256, (n_ut + 63) & ~63);
+  const int G = std::min(threads / n_ut, 16);
   const size_t lds = ((size_t)64 * 4 * T + 64) * sizeof(double);
+  int per_cu = (int)std::min<size_t>((160 * 1024) / (lds + 512), (size_t)(2048 / threads));
+  per_cu = std::max(1, std::min(per_cu, 6));
+  long long blocks = std::min<long long>((m->N + 63) / 64, (long long)per_cu * m->n_cu);
+  if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)blocks * G * D1 * D1 * sizeof(double)))) return rc;
   if ((rc = allow_lds(wgram_kernel, lds))) return rc;
-  hipLaunchKernelGGL(wgram_kernel, dim3((unsigned)blocks), dim3(T * T), lds, m->stream, m->X, (long long)m->N, D, T, (const double*)m->d_tab,
-                     (const double*)m->d_resp + (size_t)c * m->N, (double*)m->d_part);
+  hipLaunchKernelGGL(wgram_kernel, dim3((unsigned)blocks), dim3(threads), lds, m->stream, m->X, (long long)m->N, D, T, G,
+                     (const double*)m->d_tab, (const double*)m->d_resp + (size_t)c * m->N, (double*)m->d_part);
   ZK_HIP(hipGetLastError());
+  blocks *= G;
   return reduce_to_host(m, (int)blocks, D1 * D1, gram_out);
 }
