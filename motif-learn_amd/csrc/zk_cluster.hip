@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 
 struct zk_rows {
@@ -408,33 +409,61 @@ __global__ __launch_bounds__(64) void owndist_kernel(const double* __restrict__ 
   __builtin_amdgcn_s_waitcnt(0xC07F); \
   __builtin_amdgcn_sched_barrier(0)
 
-__global__ __launch_bounds__(64) void estep_kernel(const double* __restrict__ X, long long N, int D, int DP, int nbuf,
-                                                   const double* __restrict__ P, const double* __restrict__ B,
-                                                   const double* __restrict__ cst /* [k][2]: logdet, logw */, double dlog2pi, int k,
-                                                   double* __restrict__ resp, int32_t* __restrict__ labels,
-                                                   double* __restrict__ part) {
+// ZK_EWAVES waves share a tile (every wave holds the same 64 rows, lane = row): the (component, column block) pairs are dealt
+// to the waves by cost on the host (`plan`: per wave a count and its (c, j0) pairs), each wave adds the squared norms of its
+// blocks into its own [k][64] LDS table, and after a barrier every wave combines the tables in wave order -- redundant but
+// cheap arithmetic -- for the log-sum-exp; the stores of the responsibilities are split by component.
+#ifndef ZK_EWAVES
+#define ZK_EWAVES 4
+#endif
+__global__ __launch_bounds__(64 * ZK_EWAVES) void estep_kernel(const double* __restrict__ X, long long N, int D, int DP,
+                                                               const double* __restrict__ P, const double* __restrict__ B,
+                                                               const double* __restrict__ cst /* [k][2]: logdet, logw */,
+                                                               const int* __restrict__ plan, int plan_stride, double dlog2pi, int k,
+                                                               double* __restrict__ resp, int32_t* __restrict__ labels,
+                                                               double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* lp = lds + nbuf * TILE * D;  // [k][64]
-  const int lane = threadIdx.x;
+  double* tile = lds;                  // [64][D]
+  double* sqw = lds + TILE * D;        // [ZK_EWAVES][k][64]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* mine = sqw + (long long)wave * k * 64;
+  const ZK_CONST int* my_plan = (const ZK_CONST int*)plan + wave * plan_stride;
+  const int n_mine = my_plan[0];
+  const int n_gran = 32 * D;
   double lse_sum = 0.0;
-  for (tile_pipe pipe(X, N, D, lds, lane, nbuf); pipe.live(); pipe.advance()) {
-    const double* row = pipe.acquire() + lane * D;
-    double best = -std::numeric_limits<double>::infinity();
-    int bl = 0;
-    for (int c = 0; c < k; ++c) {
+  for (long long t = blockIdx.x; t * TILE < N; t += gridDim.x) {
+    __syncthreads();  // the previous tile and tables are no longer read
+    if ((t + 1) * TILE <= N) {
+      const char* src = (const char*)(X + t * TILE * D);
+      for (int q = wave; q * 64 < n_gran; q += ZK_EWAVES) {
+        const int g = q * 64 + lane;
+        if (g < n_gran) __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(src + (long long)g * 16), ZK_LDS_PTR((char*)tile + q * 1024), 16, 0, 2);
+      }
+    } else {
+      const long long base = t * TILE * D, total = N * D;
+      for (int q = wave; q < D; q += ZK_EWAVES) {
+        const long long e = base + (long long)q * TILE + lane;
+        tile[q * TILE + lane] = e < total ? X[e] : 0.0;
+      }
+    }
+    for (int c = 0; c < k; ++c) mine[c * 64 + lane] = 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const double* row = tile + lane * D;
+    for (int p = 0; p < n_mine; ++p) {
+      const int c = my_plan[1 + 2 * p], j0 = my_plan[2 + 2 * p];
       const ZK_CONST double* pc = zk_const(P) + (long long)c * D * DP;
       const ZK_CONST double* bc = zk_const(B) + (long long)c * DP;
-      double sq = 0.0;
-      // ZK_EW columns of y at a time; row i of the factor (ZK_EW wave-uniform doubles) and x_i are requested one step ahead of
-      // their FMAs (the scalar-operand pipelining of zk_sep.h: wait for this step's operands, request the next, compute).
+      // ZK_EW columns of y at a time; row i of the factor (ZK_EW wave-uniform doubles) and x_i are requested one step ahead
+      // of their FMAs (the scalar-operand pipelining of zk_sep.h: wait for this step's operands, request the next, compute).
       // The prefetch past the last row reads the next component's first row / the table that follows: in bounds.
-      for (int j0 = 0; j0 < DP; j0 += ZK_EW) {
-        double a[ZK_EW], Pn[ZK_EW];
-        const ZK_CONST double* pr = pc + j0;
+      double a[ZK_EW], Pn[ZK_EW];
+      const ZK_CONST double* pr = pc + j0;
 #pragma unroll
-        for (int jj = 0; jj < ZK_EW; ++jj) a[jj] = -bc[j0 + jj], Pn[jj] = pr[jj];
-        double xn = row[0];
-        const int imax = j0 + ZK_EW < D ? j0 + ZK_EW : D;
+      for (int jj = 0; jj < ZK_EW; ++jj) a[jj] = -bc[j0 + jj], Pn[jj] = pr[jj];
+      double xn = row[0];
+      const int imax = j0 + ZK_EW < D ? j0 + ZK_EW : D;
 #define ZK_ESTEP(NEXT)                                                                    \
   {                                                                                       \
     ZK_LGKM_WAIT();                                                                       \
@@ -446,41 +475,66 @@ __global__ __launch_bounds__(64) void estep_kernel(const double* __restrict__ X,
     __builtin_amdgcn_sched_barrier(0);                                                    \
     _Pragma("unroll") for (int jj = 0; jj < ZK_EW; ++jj) a[jj] = __builtin_fma(x, Pc[jj], a[jj]); \
   }
-        int i = 0;
-        for (; i + 3 < imax; i += 4) {
-          ZK_ESTEP(1)
-          ZK_ESTEP(2)
-          ZK_ESTEP(3)
-          ZK_ESTEP(4)
-          pr += 4 * DP;
-        }
-        for (; i < imax; ++i) {
-          ZK_ESTEP(1)
-          pr += DP;
-        }
-#undef ZK_ESTEP
-        ZK_LGKM_WAIT();
-#pragma unroll
-        for (int jj = 0; jj < ZK_EW; ++jj) sq = __builtin_fma(a[jj], a[jj], sq);
+      int i = 0;
+      for (; i + 3 < imax; i += 4) {
+        ZK_ESTEP(1)
+        ZK_ESTEP(2)
+        ZK_ESTEP(3)
+        ZK_ESTEP(4)
+        pr += 4 * DP;
       }
+      for (; i < imax; ++i) {
+        ZK_ESTEP(1)
+        pr += DP;
+      }
+#undef ZK_ESTEP
+      ZK_LGKM_WAIT();
+      double sq = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < ZK_EW; ++jj) sq = __builtin_fma(a[jj], a[jj], sq);
+      mine[c * 64 + lane] += sq;
+    }
+    __syncthreads();
+    // weighted log probabilities of the 64 rows (every wave), log-sum-exp, outputs split by component / wave
+    double best = -std::numeric_limits<double>::infinity();
+    int bl = 0;
+    for (int c = 0; c < k; ++c) {
+      double sq = 0.0;
+#pragma unroll
+      for (int w = 0; w < ZK_EWAVES; ++w) sq += sqw[((long long)w * k + c) * 64 + lane];
       const ZK_CONST double* cc = zk_const(cst) + 2 * c;
       const double v = (-0.5 * (dlog2pi + sq) + cc[0]) + cc[1];
-      lp[c * 64 + lane] = v;
       if (v > best) best = v, bl = c;
     }
     double s = 0.0;
-    for (int c = 0; c < k; ++c) s += exp(lp[c * 64 + lane] - best);
+    for (int c = 0; c < k; ++c) {
+      double sq = 0.0;
+#pragma unroll
+      for (int w = 0; w < ZK_EWAVES; ++w) sq += sqw[((long long)w * k + c) * 64 + lane];
+      const ZK_CONST double* cc = zk_const(cst) + 2 * c;
+      s += exp(((-0.5 * (dlog2pi + sq) + cc[0]) + cc[1]) - best);
+    }
     const double lse = log(s) + best;
-    const long long r = pipe.t * TILE + lane;
+    const long long r = t * TILE + lane;
     if (r < N) {
-      lse_sum += lse;
-      if (labels) labels[r] = bl;
+      if (wave == 0) {
+        lse_sum += lse;
+        if (labels) labels[r] = bl;
+      }
       if (resp)
-        for (int c = 0; c < k; ++c) __builtin_nontemporal_store(exp(lp[c * 64 + lane] - lse), resp + (long long)c * N + r);
+        for (int c = wave; c < k; c += ZK_EWAVES) {
+          double sq = 0.0;
+#pragma unroll
+          for (int w = 0; w < ZK_EWAVES; ++w) sq += sqw[((long long)w * k + c) * 64 + lane];
+          const ZK_CONST double* cc = zk_const(cst) + 2 * c;
+          __builtin_nontemporal_store(exp(((-0.5 * (dlog2pi + sq) + cc[0]) + cc[1]) - lse), resp + (long long)c * N + r);
+        }
     }
   }
-  const double tot = wave_sum(lse_sum);
-  if (lane == 0) part[blockIdx.x] = tot;
+  if (wave == 0) {
+    const double tot = wave_sum(lse_sum);
+    if (lane == 0) part[blockIdx.x] = tot;
+  }
 }
 
 // resp[c][r] = (labels[r] == c)
@@ -971,12 +1025,31 @@ extern "C" int zk_gmm_estep(zk_rows* m, const double* prec_chol, const double* m
   if (!m || !prec_chol || !means || !log_det || !log_w || !lse_sum_out) return zk_fail(ZK_E_BADARG, "null pointer");
   if (k < 1 || k > 64) return zk_fail(ZK_E_BADARG, "1 to 64 mixture components");
   ZK_ON_DEVICE(m->device);
-  const int D = m->D, DP = (D + ZK_EW - 1) / ZK_EW * ZK_EW;
+  const int D = m->D, DP = (D + ZK_EW - 1) / ZK_EW * ZK_EW, n_blk = DP / ZK_EW;
+  // the (component, column block) pairs, dealt to the waves: longest first, each to the least loaded wave
+  const int plan_stride = 1 + 2 * k * n_blk;
+  std::vector<int> plan((size_t)ZK_EWAVES * plan_stride, 0);
+  {
+    long long load[ZK_EWAVES] = {0};
+    for (int jb = n_blk - 1; jb >= 0; --jb)
+      for (int c = 0; c < k; ++c) {
+        int w = 0;
+        for (int v = 1; v < ZK_EWAVES; ++v)
+          if (load[v] < load[w]) w = v;
+        int* mine = plan.data() + (size_t)w * plan_stride;
+        mine[1 + 2 * mine[0]] = c;
+        mine[2 + 2 * mine[0]] = jb * ZK_EW;
+        ++mine[0];
+        load[w] += std::min(D, (jb + 1) * ZK_EW) + 4;
+      }
+  }
+  const size_t plan_doubles = (plan.size() * sizeof(int) + 7) / 8;
   std::vector<double>& h = m->h_buf;
-  h.assign((size_t)k * D * DP + (size_t)k * DP + 2 * (size_t)k, 0.0);
+  h.assign((size_t)k * D * DP + (size_t)k * DP + 2 * (size_t)k + plan_doubles, 0.0);
   double* P = h.data();
   double* B = P + (size_t)k * D * DP;
   double* C = B + (size_t)k * DP;
+  memcpy(C + 2 * (size_t)k, plan.data(), plan.size() * sizeof(int));
   for (int c = 0; c < k; ++c) {
     const double* pc = prec_chol + (size_t)c * D * D;
     for (int i = 0; i < D; ++i)
@@ -992,18 +1065,19 @@ extern "C" int zk_gmm_estep(zk_rows* m, const double* prec_chol, const double* m
   int rc = upload_tab(m, h);
   h.clear();
   if (rc) return rc;
-  static const int nbuf_env = getenv("ZK_ESTEP_NBUF") ? atoi(getenv("ZK_ESTEP_NBUF")) : 1;
-  const int nbuf = nbuf_env == 2 ? 2 : 1;  // the arithmetic sets the pace: one buffer, twice the waves per CU
-  const size_t lds = tile_lds(m, nbuf) + (size_t)k * 64 * sizeof(double);
+  const size_t lds = (size_t)TILE * D * sizeof(double) + (size_t)ZK_EWAVES * k * 64 * sizeof(double);
   if ((rc = check_lds(lds)) || (rc = allow_lds(estep_kernel, lds))) return rc;
-  const int grid = row_grid(m, lds);
+  int per_cu = (int)std::min<size_t>((160 * 1024) / (lds + 512), (size_t)(32 / ZK_EWAVES));
+  per_cu = std::max(1, per_cu);
+  const int grid = (int)std::min<long long>((m->N + TILE - 1) / TILE, (long long)per_cu * m->n_cu);
   if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * sizeof(double)))) return rc;
   if (want_resp && (rc = ensure(&m->d_resp, &m->resp_bytes, (size_t)k * m->N * sizeof(double)))) return rc;
   if (!m->d_labels) ZK_HIP(hipMalloc((void**)&m->d_labels, (size_t)m->N * sizeof(int32_t)));
   const double* tab = (const double*)m->d_tab;
-  hipLaunchKernelGGL(estep_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, D, DP, nbuf, tab, tab + (size_t)k * D * DP,
-                     tab + (size_t)k * D * DP + (size_t)k * DP, (double)D * std::log(2.0 * M_PI), k,
-                     want_resp ? (double*)m->d_resp : nullptr, m->d_labels, (double*)m->d_part);
+  const double* d_cst = tab + (size_t)k * D * DP + (size_t)k * DP;
+  hipLaunchKernelGGL(estep_kernel, dim3(grid), dim3(64 * ZK_EWAVES), lds, m->stream, m->X, (long long)m->N, D, DP, tab,
+                     tab + (size_t)k * D * DP, d_cst, (const int*)(d_cst + 2 * (size_t)k), plan_stride,
+                     (double)D * std::log(2.0 * M_PI), k, want_resp ? (double*)m->d_resp : nullptr, m->d_labels, (double*)m->d_part);
   ZK_HIP(hipGetLastError());
   return reduce_to_host(m, grid, 1, lse_sum_out);
 }
