@@ -82,5 +82,21 @@ with open(os.path.join(P, f"{TAG}_sq_counters.txt"), "w") as f:
                 f"{v['SQ_INSTS_SALU'] / v['SQ_INSTS_VALU']:9.3f} {v['SQ_WAIT_ANY'] / wc:8.3f} {v['SQ_WAIT_INST_ANY'] / wc:9.3f} "
                 f"{v['SQ_LDS_BANK_CONFLICT']:12.0f} {v['SQ_INSTS_SMEM'] / v['SQ_INSTS_VALU']:9.3f}\n")
     f.write("\n# raw means\n" + sq)
+cl = os.path.join(G, f"{TAG}_cluster", "c_kernel_stats.csv")
+if os.path.exists(cl):
+    log = [l.rstrip() for l in open(os.path.join(G, f"{TAG}_cluster.log")) if l.startswith(("matrix", "  ", "kmeans_fit", "gmm_fit"))]
+    with open(os.path.join(P, f"{TAG}_cluster_kernel_stats.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 motif-learn_amd/tools/time_clustering.py   (1 x MI355X)\n")
+        f.write("# clustering consumers (csrc/zk_cluster.hip) on a resident 4 068 289 x 45 float64 matrix (1.46 GB), k = 6; the tool's own\n")
+        f.write("# wall-clock lines (synchronous C-ABI calls: table upload + kernel + reduction + a few hundred bytes back):\n")
+        for l in log:
+            f.write("#   " + l + "\n")
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+        for r in csv.DictReader(open(cl)):
+            if "_kernel" in r["Name"]:
+                name = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+                w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"]])
+    print(open(os.path.join(P, f"{TAG}_cluster_kernel_stats.csv")).read())
 print(open(os.path.join(P, f"{TAG}_kernel_stats_bench.csv")).read())
 print(open(os.path.join(P, f"{TAG}_sq_counters.txt")).read().split("# raw means")[0])
