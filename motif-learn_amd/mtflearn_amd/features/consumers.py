@@ -11,8 +11,8 @@ scikit-learn is a dependency of the reference and of this package, so parity is 
 usual case: millions of patches x 45 moments); for smaller inputs it uses an SVD of the centred matrix, which this
 routine does not imitate -- same subspace and signs, last digits may differ.
 
-The reference's clustering wrappers (``kmeans_lbs`` / ``gmm_lbs``: scikit-learn estimators with their own random
-initialisation) and ``ForceGraph8`` (a numba layout optimiser) are not rebuilt.
+The reference's clustering wrappers (``kmeans_lbs`` / ``gmm_lbs``) live in ``mtflearn_amd.clustering``; ``ForceGraph8`` (a
+sequential numba layout optimiser) is not rebuilt.
 """
 from __future__ import annotations
 
