@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   north_star_4096, config2_batch, config2_dense, config3_per_gpu, dense_frame, symmetry_pipeline -- the other
                     BASELINE configs as far as one GPU carries them, each with its own roofline object (N = 1)
   host_api       -- NumPy in / NumPy out through ZPs.transform (PCIe-inclusive; never `value`)
+  clustering     -- the k-means consumer on the moment matrix where the timed kernel left it (N > 1: sharded, labels gathered)
   multi_frame, sharded_maps -- configs[3] / configs[4] on N > 1 ranks
 """
 import argparse
@@ -58,6 +59,7 @@ def parse():
     ap.add_argument("--no-host-api", action="store_true", help="skip the NumPy-in / NumPy-out measurement")
     ap.add_argument("--no-multi-frame", action="store_true", help="N>1: skip configs[3] (8 frames per rank)")
     ap.add_argument("--only-timed-loop", action="store_true", help="skip every side measurement (profiling runs)")
+    ap.add_argument("--no-clustering", action="store_true", help="skip the k-means consumer on the resident moment matrix")
     return ap.parse_args()
 
 
@@ -298,6 +300,8 @@ def worker(args):
     in_step = world > 1 and not args.kernel_only_value
     elapsed, launches, kernel_ms = (el_gather, l_gather, ms_gather) if in_step else (el_kernel, l_kernel, ms_kernel)
     side = {}
+    if not args.only_timed_loop and not args.no_clustering:
+        side["clustering"] = clustering_section(comm, world, dev, mine, n_local, n_poly)
     if world > 1 and not args.only_timed_loop:
         side.update(multi_rank_sections(args, comm, rank, world, dev, plan, z))
 
@@ -349,6 +353,40 @@ def worker(args):
     if comm is not None:
         comm.barrier()
         comm.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# downstream consumer on the moment matrix where the timed kernel left it (every rank takes part; rank 0 reports):
+# k-means of ALL ranks' moments without gathering them -- the ranks exchange k x D sums, then 4 bytes of label per row
+# ---------------------------------------------------------------------------------------------------------
+def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4):
+    import numpy as np
+    import torch
+    from mtflearn_amd.clustering import DeviceRows, kmeans_fit, gather_labels
+    torch.cuda.synchronize()
+    worst = (lambda v: comm.max_over_ranks(v)) if comm is not None else (lambda v: v)
+    rows = DeviceRows.adopt(mine.data_ptr(), n_local, n_poly, device=dev.index)
+    try:
+        t0 = time.perf_counter()
+        labels, _, n_iter = kmeans_fit(rows, k, random_state=0, comm=comm)
+        s_fit = worst(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        whole = gather_labels(labels, comm)
+        s_gather = worst(time.perf_counter() - t0)
+    finally:
+        rows.close()
+    sizes = np.bincount(whole, minlength=k).astype(np.int64)
+    agree = True
+    if comm is not None:
+        agree = all(b == sizes.tobytes() for b in comm.allgather_host(sizes.tobytes()))
+    n_total = world * n_local
+    return {"workload": f"kmeans_lbs flow (scikit-learn KMeans(n_clusters={k}, random_state=0): k-means++ seeding, Lloyd) on the "
+                        f"({n_total}, {n_poly}) float64 moment matrix of the timed step, resident in HBM, "
+                        + (f"one block per rank: the ranks exchange {k} x {n_poly + 1} sums per pass and gather 4-byte labels, "
+                           "never the moments" if world > 1 else "adopted where the batch kernel wrote it"),
+            "k": k, "lloyd_iterations": n_iter, "s_fit": s_fit, "s_label_gather": s_gather,
+            "rows_per_s_end_to_end": n_total / (s_fit + s_gather), "cluster_sizes": sizes.tolist(), "ranks_agree": bool(agree),
+            "label_bytes_gathered": 4 * n_total, "moment_bytes_not_gathered": 8 * n_poly * n_total}
 
 
 # ---------------------------------------------------------------------------------------------------------

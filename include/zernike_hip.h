@@ -276,7 +276,8 @@ int zk_comm_world(const zk_comm* comm);
 int zk_allgather_rows(zk_comm* comm, double* full_dev, int64_t n_planes, int64_t height, int64_t width,
                       int64_t rows_per_rank, int64_t row_off, int64_t n_rows, void* hip_stream);
 int zk_comm_join(zk_comm* comm, void* hip_stream);
-/* Blocking all-gather of a few host bytes per rank (timings, checksums; doubles as a barrier). */
+/* Blocking all-gather of the same number of host bytes from every rank (timings, checksums, the k x D sums of a sharded
+ * k-means step; doubles as a barrier).  Up to 64 MiB per rank. */
 int zk_comm_allgather_host(zk_comm* comm, const void* send_host, void* recv_host, int64_t bytes_per_rank);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -348,6 +349,10 @@ const double* zk_rows_data(const zk_rows* rows);                 /* the device m
 /* Column means and population variances (two passes, as numpy.mean / numpy.var); the means become the centring shift of
  * the k-means calls (scikit-learn subtracts them before clustering); n_bad_out = rows with a non-finite element. */
 int zk_rows_center(zk_rows* rows, double* mean_out, double* var_out, int64_t* n_bad_out);
+/* The two halves of zk_rows_center for a matrix whose rows are spread over several ranks: local column sums; then, with the
+ * mean over ALL ranks, the local sums of squared deviations (and the centring shift, row norms, finiteness count). */
+int zk_rows_colsum(zk_rows* rows, double* sums_out);
+int zk_rows_center_at(zk_rows* rows, const double* mean, double* sqsum_out, int64_t* n_bad_out);
 int zk_rows_fetch(zk_rows* rows, const int64_t* idx, int n, int centred, double* rows_out);   /* (n, D) to the host */
 int zk_rows_reset_labels(zk_rows* rows);                         /* labels := -1 (a new k-means run) */
 int zk_rows_labels(zk_rows* rows, int32_t* labels_host);         /* (N) labels of the last k-means / E step */

@@ -760,30 +760,40 @@ extern "C" int zk_rows_create(int device, const double* X_host, int64_t N, int D
 
 extern "C" const double* zk_rows_data(const zk_rows* m) { return m ? m->X : nullptr; }
 
-// Column means (mean_out) and population variances about them (var_out), two passes as numpy.mean / numpy.var; the means
-// become the centring shift of every later k-means call; n_bad_out = rows with a non-finite element.
-extern "C" int zk_rows_center(zk_rows* m, double* mean_out, double* var_out, int64_t* n_bad_out) {
-  if (!m || !mean_out || !var_out || !n_bad_out) return zk_fail(ZK_E_BADARG, "null pointer");
+// Column sums of the matrix (first pass of numpy.mean).
+extern "C" int zk_rows_colsum(zk_rows* m, double* sums_out) {
+  if (!m || !sums_out) return zk_fail(ZK_E_BADARG, "null pointer");
   ZK_ON_DEVICE(m->device);
   const int nbuf = tile_bufs(m);
   const size_t lds = tile_lds(m, nbuf);
   int rc = check_lds(lds);
-  if (rc) return rc;
-  if ((rc = allow_lds(colsum_kernel, lds)) || (rc = allow_lds(rownorm_kernel, lds))) return rc;
+  if (rc || (rc = allow_lds(colsum_kernel, lds))) return rc;
   const int grid = row_grid(m, lds);
   if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * m->D * sizeof(double)))) return rc;
   hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, nbuf, (const double*)nullptr, 0,
                      (double*)m->d_part);
   ZK_HIP(hipGetLastError());
-  if ((rc = reduce_to_host(m, grid, m->D, mean_out))) return rc;
-  for (int j = 0; j < m->D; ++j) mean_out[j] /= (double)m->N;
-  ZK_HIP(hipMemcpyAsync(m->d_mean, mean_out, (size_t)m->D * sizeof(double), hipMemcpyHostToDevice, m->stream));
+  return reduce_to_host(m, grid, m->D, sums_out);
+}
+
+// `mean` (D) becomes the centring shift of every later k-means call (scikit-learn subtracts the column means before
+// clustering; with several ranks it is the mean over all of them); sqsum_out[j] = sum_r (x_rj - mean_j)^2 (second pass of
+// numpy.var), the squared norms of the centred rows stay on the device, n_bad_out = rows with a non-finite element.
+extern "C" int zk_rows_center_at(zk_rows* m, const double* mean, double* sqsum_out, int64_t* n_bad_out) {
+  if (!m || !mean || !sqsum_out || !n_bad_out) return zk_fail(ZK_E_BADARG, "null pointer");
+  ZK_ON_DEVICE(m->device);
+  const int nbuf = tile_bufs(m);
+  const size_t lds = tile_lds(m, nbuf);
+  int rc = check_lds(lds);
+  if (rc || (rc = allow_lds(colsum_kernel, lds)) || (rc = allow_lds(rownorm_kernel, lds))) return rc;
+  const int grid = row_grid(m, lds);
+  if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * m->D * sizeof(double)))) return rc;
+  ZK_HIP(hipMemcpyAsync(m->d_mean, mean, (size_t)m->D * sizeof(double), hipMemcpyHostToDevice, m->stream));
   ZK_HIP(hipStreamSynchronize(m->stream));
   hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, nbuf, (const double*)m->d_mean, 1,
                      (double*)m->d_part);
   ZK_HIP(hipGetLastError());
-  if ((rc = reduce_to_host(m, grid, m->D, var_out))) return rc;
-  for (int j = 0; j < m->D; ++j) var_out[j] /= (double)m->N;
+  if ((rc = reduce_to_host(m, grid, m->D, sqsum_out))) return rc;
   if (!m->d_xsq) ZK_HIP(hipMalloc((void**)&m->d_xsq, (size_t)m->N * sizeof(double)));
   ZK_HIP(hipMemsetAsync(m->d_count, 0, sizeof(unsigned long long), m->stream));
   hipLaunchKernelGGL(rownorm_kernel, dim3(grid), dim3(64), lds, m->stream, m->X, (long long)m->N, m->D, nbuf, (const double*)m->d_mean,
@@ -793,6 +803,18 @@ extern "C" int zk_rows_center(zk_rows* m, double* mean_out, double* var_out, int
   ZK_HIP(hipMemcpyAsync(&bad, m->d_count, sizeof(bad), hipMemcpyDeviceToHost, m->stream));
   ZK_HIP(hipStreamSynchronize(m->stream));
   *n_bad_out = (int64_t)bad;
+  return 0;
+}
+
+// Column means (mean_out) and population variances about them (var_out), two passes as numpy.mean / numpy.var, of THIS
+// matrix alone (= zk_rows_colsum, division, zk_rows_center_at, division).
+extern "C" int zk_rows_center(zk_rows* m, double* mean_out, double* var_out, int64_t* n_bad_out) {
+  if (!m || !mean_out || !var_out || !n_bad_out) return zk_fail(ZK_E_BADARG, "null pointer");
+  int rc = zk_rows_colsum(m, mean_out);
+  if (rc) return rc;
+  for (int j = 0; j < m->D; ++j) mean_out[j] /= (double)m->N;
+  if ((rc = zk_rows_center_at(m, mean_out, var_out, n_bad_out))) return rc;
+  for (int j = 0; j < m->D; ++j) var_out[j] /= (double)m->N;
   return 0;
 }
 

@@ -143,7 +143,8 @@ struct zk_comm {
   hipStream_t stream = nullptr;   // collectives run here
   hipEvent_t ev_in = nullptr;     // producer stream -> comm stream
   hipEvent_t ev_out = nullptr;    // comm stream -> consumer stream
-  void* d_small = nullptr;        // zk_comm_allgather_host staging: world * 256 B
+  void* d_small = nullptr;        // zk_comm_allgather_host staging: (world + 1) * small_unit bytes, grows on demand
+  size_t small_unit = 256;
   int algo = 0;                   // 0 auto, 1 p2p, 2 allgather, 3 bcast
 };
 
@@ -421,10 +422,17 @@ extern "C" int zk_comm_join(zk_comm* c, void* hip_stream) {
 
 extern "C" int zk_comm_allgather_host(zk_comm* c, const void* send_host, void* recv_host, int64_t bytes) {
   if (!c) return zk_fail(ZK_E_BADARG, "null communicator");
-  if (bytes <= 0 || bytes > 256 || !send_host || !recv_host) return zk_fail(ZK_E_BADARG, "1..256 bytes per rank");
+  if (bytes <= 0 || bytes > (1 << 26) || !send_host || !recv_host) return zk_fail(ZK_E_BADARG, "1 byte to 64 MiB per rank");
   ZK_ON_DEVICE(c->device);
+  if ((size_t)bytes > c->small_unit) {  // every rank passes the same size, so every rank grows at the same call
+    ZK_HIP(hipStreamSynchronize(c->stream));
+    ZK_HIP(hipFree(c->d_small));
+    c->d_small = nullptr;
+    c->small_unit = ((size_t)bytes + 4095) & ~(size_t)4095;
+    ZK_HIP(hipMalloc(&c->d_small, (size_t)(c->world + 1) * c->small_unit));
+  }
   char* d = (char*)c->d_small;
-  char* d_send = d + (size_t)c->world * 256;
+  char* d_send = d + (size_t)c->world * c->small_unit;
   ZK_HIP(hipMemcpyAsync(d_send, send_host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
   if (c->world == 1) {
     ZK_HIP(hipMemcpyAsync(d, d_send, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream));

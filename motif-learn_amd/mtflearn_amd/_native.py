@@ -95,6 +95,8 @@ SYMBOLS = {
     "zk_rows_destroy": (c_int, [c_void_p]),
     "zk_rows_data": (c_void_p, [c_void_p]),
     "zk_rows_center": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "zk_rows_colsum": (c_int, [c_void_p, POINTER(c_double)]),
+    "zk_rows_center_at": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
     "zk_rows_fetch": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, POINTER(c_double)]),
     "zk_rows_reset_labels": (c_int, [c_void_p]),
     "zk_rows_labels": (c_int, [c_void_p, POINTER(c_int32)]),
@@ -467,7 +469,7 @@ class Comm:
         check(self._lib.zk_comm_join(self._h, c_void_p(stream)), "zk_comm_join")
 
     def allgather_host(self, payload: bytes):
-        """Blocking all-gather of up to 256 host bytes per rank; returns the list of every rank's bytes."""
+        """Blocking all-gather of the same number of host bytes from every rank; returns the list of every rank's bytes."""
         n = len(payload)
         send = ctypes.create_string_buffer(payload, n)
         recv = ctypes.create_string_buffer(n * self.world)

@@ -27,7 +27,7 @@ import numpy as np
 from . import _native
 from .features.pickers import _device
 
-__all__ = ["kmeans_lbs", "gmm_lbs", "sort_lbs", "DeviceRows", "kmeans_fit", "gmm_fit_predict"]
+__all__ = ["kmeans_lbs", "gmm_lbs", "sort_lbs", "DeviceRows", "kmeans_fit", "gmm_fit_predict", "gather_labels"]
 
 _PD = POINTER(c_double)
 
@@ -58,7 +58,6 @@ class DeviceRows:
             _native.check(self._lib.zk_rows_create(self.device, _p(X), n, d, byref(handle)), "zk_rows_create")
         self._h = handle
         self.n_rows, self.n_features = int(n), int(d)
-        self._stats = None
 
     @classmethod
     def adopt(cls, device_pointer, n_rows, n_features, device=None):
@@ -79,13 +78,17 @@ class DeviceRows:
         self.close()
 
     # ---- passes ----------------------------------------------------------------------------------------------------
-    def center(self):
-        """(column means, population variances, number of rows with a non-finite element); cached."""
-        if self._stats is None:
-            mean, var, bad = np.empty(self.n_features), np.empty(self.n_features), c_int64()
-            _native.check(self._lib.zk_rows_center(self._h, _p(mean), _p(var), byref(bad)), "zk_rows_center")
-            self._stats = (mean, var, int(bad.value))
-        return self._stats
+    def colsum(self):
+        out = np.empty(self.n_features)
+        _native.check(self._lib.zk_rows_colsum(self._h, _p(out)), "zk_rows_colsum")
+        return out
+
+    def center_at(self, mean):
+        """Make ``mean`` the centring shift; returns (sums of squared deviations per column, rows with a non-finite element)."""
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        sq, bad = np.empty(self.n_features), c_int64()
+        _native.check(self._lib.zk_rows_center_at(self._h, _p(mean), _p(sq), byref(bad)), "zk_rows_center_at")
+        return sq, int(bad.value)
 
     def fetch(self, idx, centred=True):
         idx = np.ascontiguousarray(idx, dtype=np.int64).ravel()
@@ -153,9 +156,78 @@ def _as_rows(X):
     return (X, False) if isinstance(X, DeviceRows) else (DeviceRows(X), True)
 
 
-def _check_finite(rows):
-    if rows.center()[2]:
-        raise ValueError("Input X contains NaN or infinity.")
+class _Shards:
+    """The rows of one matrix spread over the ranks of a communicator (rank order = row order), or all of them here
+    (``comm`` None).  Everything the clustering control flow needs from the other ranks is a sum of small arrays, taken in
+    rank order on every rank (``comm.allgather_host``: the same bits everywhere), or a row fetched from its owner: no rank
+    ever sees another rank's block of the matrix."""
+
+    def __init__(self, rows, comm=None):
+        self.rows, self.comm = rows, comm
+        if comm is None or comm.world == 1:
+            self.comm = None
+            self.counts = np.array([rows.n_rows], dtype=np.int64)
+            self.rank = 0
+        else:
+            self.counts = self.gather(np.array([rows.n_rows], dtype=np.int64))[:, 0]
+            self.rank = comm.rank
+        self.offsets = np.concatenate([[0], np.cumsum(self.counts)])
+        self.total = int(self.offsets[-1])
+        self._stats = None
+
+    def gather(self, arr):
+        """Every rank's copy of a small float64 / int64 array -> (world, ...)."""
+        arr = np.ascontiguousarray(arr)
+        if self.comm is None:
+            return arr[None]
+        return np.stack([np.frombuffer(b, dtype=arr.dtype).reshape(arr.shape) for b in self.comm.allgather_host(arr.tobytes())])
+
+    def sum(self, arr):
+        parts = self.gather(arr)
+        out = parts[0].copy()
+        for part in parts[1:]:
+            out += part
+        return out
+
+    def center(self):
+        """(mean, population variance, rows with a non-finite element) of the whole matrix; sets the centring shift."""
+        cached = getattr(self.rows, "_center_cache", None) if self.comm is None else None
+        if self._stats is None and cached is not None:
+            self._stats = cached                                             # one block: the shift is already the block's mean
+        if self._stats is None:
+            mean = self.sum(self.rows.colsum()) / self.total
+            sq, bad = self.rows.center_at(mean)
+            self._stats = (mean, self.sum(sq) / self.total, int(self.sum(np.array([bad], dtype=np.int64))[0]))
+            self.rows._center_cache = self._stats if self.comm is None else None
+        return self._stats
+
+    def check_finite(self):
+        if self.center()[2]:
+            raise ValueError("Input X contains NaN or infinity.")
+
+    def fetch(self, global_ids):
+        """Centred rows by global index, from whichever rank holds each."""
+        ids = np.asarray(global_ids, dtype=np.int64).ravel()
+        lo, hi = self.offsets[self.rank], self.offsets[self.rank + 1]
+        mine = (ids >= lo) & (ids < hi)
+        out = np.zeros((len(ids), self.rows.n_features))
+        if mine.any():
+            out[mine] = self.rows.fetch(ids[mine] - lo)
+        return out if self.comm is None else self.sum(out)          # every row has exactly one owner: the others add zeros
+
+    def search(self, which, vals, local_total):
+        """``searchsorted(cumsum(closest), vals)`` over the whole matrix: the owner of each value follows from the ranks'
+        totals, the position inside its block is found by that rank; also adopts candidate ``which`` as the closest-distance
+        row on every rank."""
+        vals = np.asarray(vals, dtype=np.float64)
+        ends = np.cumsum(self.gather(np.array([local_total], dtype=np.float64))[:, 0])
+        last_holder = np.flatnonzero(self.counts > 0)[-1]
+        owner = np.minimum(np.searchsorted(ends, vals), last_holder)
+        before = np.concatenate([[0.0], ends])[owner]
+        mine = owner == self.rank
+        found = np.full(len(vals), -1, dtype=np.int64)
+        found[mine] = self.rows.seed_pick(which, (vals - before)[mine]) + self.offsets[self.rank]
+        return found if self.comm is None else self.gather(found).max(axis=0)
 
 
 # ---------------------------------------------------------------------------------------------------------- k-means
@@ -163,23 +235,25 @@ def _row_norms_sq(a):
     return np.einsum("ij,ij->i", a, a)                                       # sklearn.utils.extmath.row_norms(squared=True)
 
 
-def _kmeans_plusplus(rows, n_clusters, random_state):
+def _kmeans_plusplus(sh, n_clusters, random_state):
     """``_kmeans_plusplus`` (sklearn/cluster/_kmeans.py) on the centred matrix: same draws, distances on the device."""
-    n = rows.n_rows
+    rows, n = sh.rows, sh.total
     n_local_trials = 2 + int(np.log(n_clusters))
     centers = np.empty((n_clusters, rows.n_features))
     indices = np.full(n_clusters, -1, dtype=int)
     weight = np.ones(n)
     center_id = random_state.choice(n, p=weight / weight.sum())
-    centers[0] = rows.fetch([center_id])[0]
+    centers[0] = sh.fetch([center_id])[0]
     indices[0] = center_id
-    current_pot = rows.seed_step(centers[:1], _row_norms_sq(centers[:1]), use_closest=False)[0]
+    local_pots = rows.seed_step(centers[:1], _row_norms_sq(centers[:1]), use_closest=False)
+    current_pot = sh.sum(local_pots)[0]
     which = 0
     for c in range(1, n_clusters):
         rand_vals = random_state.uniform(size=n_local_trials) * current_pot
-        candidate_ids = rows.seed_pick(which, rand_vals)                     # searchsorted(stable_cumsum(closest), rand_vals)
-        cand = rows.fetch(candidate_ids)
-        pots = rows.seed_step(cand, _row_norms_sq(cand), use_closest=True)
+        candidate_ids = sh.search(which, rand_vals, local_pots[which])       # searchsorted(stable_cumsum(closest), rand_vals)
+        cand = sh.fetch(candidate_ids)
+        local_pots = rows.seed_step(cand, _row_norms_sq(cand), use_closest=True)
+        pots = sh.sum(local_pots)
         which = int(np.argmin(pots))
         current_pot = pots[which]
         centers[c] = cand[which]
@@ -187,47 +261,70 @@ def _kmeans_plusplus(rows, n_clusters, random_state):
     return centers, indices
 
 
-def _relocate_empty_clusters(rows, centers_old, centers_new, counts):
+def _relocate_empty_clusters(sh, centers_old, centers_new, counts):
     """``_relocate_empty_clusters_dense`` (sklearn/cluster/_k_means_common.pyx): the points farthest from their centres
-    become the centres of the empty clusters; labels are left as they are."""
+    become the centres of the empty clusters; labels are left as they are.  (Several ranks: each offers its own farthest
+    points and the farthest of all are taken in descending order -- scikit-learn's order among them is that of
+    ``numpy.argpartition``, which only a single block can reproduce.)"""
     empty = np.where(counts == 0)[0]
     if len(empty) == 0:
         return
+    rows, n_empty = sh.rows, len(empty)
     distances = rows.own_distance(centers_old)
-    far = np.argpartition(distances, -len(empty))[:-len(empty) - 1:-1]
-    labels = rows.labels()
-    points = rows.fetch(far)
-    for new_id, far_idx, x in zip(empty, far, points):
-        old_id = labels[far_idx]
+    if sh.comm is None:
+        far = np.argpartition(distances, -n_empty)[:-n_empty - 1:-1]
+        old_ids = rows.labels()[far]
+        points = rows.fetch(far)
+    else:
+        take = min(n_empty, rows.n_rows)
+        local = np.argsort(distances)[::-1][:take]
+        offer = np.full((n_empty, 3), -np.inf)                               # (distance, global index, label)
+        offer[:take, 0] = distances[local]
+        offer[:take, 1] = local + sh.offsets[sh.rank]
+        offer[:take, 2] = rows.labels()[local]
+        offers = sh.gather(offer).reshape(-1, 3)
+        best = offers[np.argsort(-offers[:, 0], kind="stable")[:n_empty]]
+        old_ids = best[:, 2].astype(np.int64)
+        points = sh.fetch(best[:, 1].astype(np.int64))
+    for new_id, old_id, x in zip(empty, old_ids, points):
         centers_new[old_id] -= x
         centers_new[new_id] = x
         counts[new_id] = 1.0
         counts[old_id] -= 1.0
 
 
-def kmeans_fit(X, n_clusters, random_state=0, max_iter=300, tol=1e-4):
+def kmeans_fit(X, n_clusters, random_state=0, max_iter=300, tol=1e-4, comm=None):
     """``KMeans(n_clusters, random_state=random_state)`` with scikit-learn's defaults (k-means++ seeding, one run, Lloyd):
-    returns ``(labels int32 (N), cluster_centers (k, D), n_iter)``.  ``X``: array or ``DeviceRows``."""
+    returns ``(labels int32 (N), cluster_centers (k, D), n_iter)``.  ``X``: array or ``DeviceRows``.
+
+    With ``comm`` (``mtflearn_amd.distributed.RcclComm`` / ``TorchComm``) ``X`` is this rank's block of rows of a matrix
+    spread over the ranks in rank order -- e.g. the moments each GPU computed -- and the clustering is that of the whole
+    matrix: the ranks exchange ``k x D`` sums per iteration, never rows of the matrix (no all-gather of the moments); the
+    returned labels are this rank's block.  Every rank must pass the same ``random_state``."""
     from sklearn.utils import check_random_state
     rows, own = _as_rows(X)
     try:
+        sh = _Shards(rows, comm)
         if not isinstance(n_clusters, (int, np.integer)) or n_clusters < 1:
             raise ValueError(f"The 'n_clusters' parameter of KMeans must be an int in the range [1, inf). Got {n_clusters!r} instead.")
-        if rows.n_rows < n_clusters:
-            raise ValueError(f"n_samples={rows.n_rows} should be >= n_clusters={n_clusters}.")
+        if sh.total < n_clusters:
+            raise ValueError(f"n_samples={sh.total} should be >= n_clusters={n_clusters}.")
         if n_clusters > 256:
             raise ValueError("at most 256 clusters on the device")
-        _check_finite(rows)
-        mean, var, _ = rows.center()
+        sh.check_finite()
+        mean, var, _ = sh.center()
         tol_abs = np.mean(var) * tol                                         # _tolerance(X, tol)
         rs = check_random_state(random_state)
-        centers, _ = _kmeans_plusplus(rows, n_clusters, rs)
+        centers, _ = _kmeans_plusplus(sh, n_clusters, rs)
         rows.reset_labels()
         strict = False
         n_iter = 0
         for n_iter in range(1, max_iter + 1):                                # _kmeans_single_lloyd
             sums, counts, n_changed = rows.lloyd(centers, update=True)
-            _relocate_empty_clusters(rows, centers, sums, counts)
+            if sh.comm is not None:
+                sums, counts = sh.sum(sums), sh.sum(counts)
+                n_changed = int(sh.sum(np.array([n_changed], dtype=np.int64))[0])
+            _relocate_empty_clusters(sh, centers, sums, counts)
             centers_new = sums
             filled = counts > 0
             centers_new[filled] *= (1.0 / counts[filled])[:, None]           # _average_centers
@@ -241,14 +338,26 @@ def kmeans_fit(X, n_clusters, random_state=0, max_iter=300, tol=1e-4):
         if not strict:
             rows.lloyd(centers, update=False)                                # labels consistent with the final centres
         labels = rows.labels()
-        if len(np.unique(labels)) < n_clusters:
+        present = sh.sum(np.bincount(labels, minlength=n_clusters).astype(np.int64))
+        if np.count_nonzero(present) < n_clusters:
             from sklearn.exceptions import ConvergenceWarning
-            warnings.warn(f"Number of distinct clusters ({len(np.unique(labels))}) found smaller than n_clusters "
+            warnings.warn(f"Number of distinct clusters ({np.count_nonzero(present)}) found smaller than n_clusters "
                           f"({n_clusters}). Possibly due to duplicate points in X.", ConvergenceWarning, stacklevel=2)
         return labels, centers + mean, n_iter
     finally:
         if own:
             rows.close()
+
+
+def gather_labels(labels, comm):
+    """Every rank's block of labels -> the labels of the whole matrix on every rank (4 bytes per row: at n_max 8 that is
+    1 / 90 of what gathering the moments would move)."""
+    if comm is None or comm.world == 1:
+        return labels
+    counts = [np.frombuffer(b, dtype=np.int64)[0] for b in comm.allgather_host(np.int64(len(labels)).tobytes())]
+    padded = np.zeros(max(counts), dtype=labels.dtype)
+    padded[:len(labels)] = labels
+    return np.concatenate([np.frombuffer(b, dtype=labels.dtype)[:n] for b, n in zip(comm.allgather_host(padded.tobytes()), counts)])
 
 
 def _relabel_by_size(lbs):
@@ -267,10 +376,11 @@ def _relabel_by_size(lbs):
     return np.vectorize(order_dict.get)(lbs)             # a label without a cluster: the reference's own call (raises)
 
 
-def kmeans_lbs(X, n=None, random_state=0):
-    """Drop-in for ``mtflearn.clustering.kmeans_lbs`` (reference ``_clustering_functions.py:8-22``)."""
-    labels, _, _ = kmeans_fit(X, n, random_state=random_state)
-    return _relabel_by_size(labels)
+def kmeans_lbs(X, n=None, random_state=0, comm=None):
+    """Drop-in for ``mtflearn.clustering.kmeans_lbs`` (reference ``_clustering_functions.py:8-22``).  With ``comm``: ``X`` is
+    this rank's block of rows (see ``kmeans_fit``); the labels of the WHOLE matrix are returned on every rank."""
+    labels, _, _ = kmeans_fit(X, n, random_state=random_state, comm=comm)
+    return _relabel_by_size(gather_labels(labels, comm))
 
 
 def sort_lbs(lbs):
@@ -356,8 +466,9 @@ def gmm_fit_predict(X, n_components, covariance_type="full", random_state=0, tol
             raise ValueError(f"Expected n_samples >= n_components but got n_components = {k}, n_samples = {n}")
         if k > 64:
             raise ValueError("at most 64 mixture components on the device")
-        _check_finite(rows)
-        shift = rows.center()[0]
+        sh = _Shards(rows)
+        sh.check_finite()
+        shift = sh.center()[0]
         rs = check_random_state(random_state)
         kmeans_fit(rows, k, random_state=rs)                                 # _initialize_parameters, init_params='kmeans'
         rows.resp_from_labels(k)

@@ -6,7 +6,7 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "motif-learn_amd"))
-from mtflearn_amd.clustering import DeviceRows, kmeans_fit, gmm_fit_predict, _row_norms_sq
+from mtflearn_amd.clustering import DeviceRows, kmeans_fit, gmm_fit_predict, _row_norms_sq, _Shards
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 N = int(args[0]) if len(args) > 0 else 4068289
@@ -30,7 +30,7 @@ def timed(label, fn, reps=5, bytes_=gb):
     return out
 
 
-t0 = time.perf_counter(); mean, var, bad = rows.center(); print(f"  center (3 passes)                  {(time.perf_counter() - t0) * 1e3:8.3f} ms")
+t0 = time.perf_counter(); mean, var, bad = _Shards(rows).center(); print(f"  center (3 passes)                  {(time.perf_counter() - t0) * 1e3:8.3f} ms")
 cand = rows.fetch(rng.integers(0, N, 4))
 timed("seed step, 4 candidates (first)", lambda: rows.seed_step(cand, _row_norms_sq(cand), False))
 rows.seed_pick(0)

@@ -1,4 +1,5 @@
 """pca on the device against scikit-learn's PCA, which is what the reference's pca() calls."""
+import os
 import warnings
 
 import numpy as np
@@ -116,3 +117,31 @@ def test_gmm_matches_sklearn_on_moment_matrices():
             labels, n_iter, converged = gmm_fit_predict(data, k, covariance_type=kind, random_state=0)
         assert np.mean(labels == ref) >= 0.999, (data.shape, k, kind, np.mean(labels == ref), n_iter, model.n_iter_)
         assert n_iter == model.n_iter_ and converged == model.converged_
+
+
+def test_kmeans_on_the_matrix_where_the_batch_kernel_left_it():
+    """The device-resident flow: patches -> zk_transform_patches_dev -> DeviceRows.adopt -> labels; the moments never visit
+    the host before the comparison copy.  Also through a world-1 RCCL communicator (the sharded code path's entry)."""
+    import torch
+    from sklearn.cluster import KMeans
+    from mtflearn_amd import ZPs, distributed as D
+    from mtflearn_amd.clustering import DeviceRows, kmeans_fit, kmeans_lbs, _relabel_by_size
+    from mtflearn_amd.synthetic import honeycomb_frame
+    frame = torch.from_numpy(honeycomb_frame(256, seed=2)).cuda()
+    patches = frame.unfold(0, 32, 2).unfold(1, 32, 2).reshape(-1, 32, 32).contiguous()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plan = ZPs(8, 32)._device_plan()
+    moments = D.patch_moments_device(plan, patches)
+    torch.cuda.synchronize()
+    ref = KMeans(n_clusters=5, random_state=0).fit(moments.cpu().numpy())
+    with DeviceRows.adopt(moments.data_ptr(), moments.shape[0], moments.shape[1], device=0) as rows:
+        labels, centers, n_iter = kmeans_fit(rows, 5, random_state=0)
+        assert np.mean(labels == ref.labels_) >= 0.999 and n_iter == ref.n_iter_
+        comm = D.RcclComm(0, 0, 1, path=f"/tmp/zk_test_cluster_{os.getpid()}.id")
+        try:
+            np.testing.assert_array_equal(kmeans_fit(rows, 5, random_state=0, comm=comm)[0], labels)
+            np.testing.assert_array_equal(kmeans_lbs(rows, 5, comm=comm), _relabel_by_size(labels))
+        finally:
+            comm.close()
+    assert torch.isfinite(moments).all()                         # an adopted matrix is borrowed, not freed
