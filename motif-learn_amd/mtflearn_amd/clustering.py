@@ -397,15 +397,16 @@ _CHOL_ERROR = ("Fitting the mixture model failed because some components have il
                "scale the input data.")
 
 
-def _gaussian_parameters(rows, k, shift, reg_covar, covariance_type):
+def _gaussian_parameters(sh, k, shift, reg_covar, covariance_type):
     """``_estimate_gaussian_parameters`` (sklearn/mixture/_gaussian_mixture.py) from the device's weighted moments about
     ``shift``: (nk, means, covariances)."""
+    rows = sh.rows
     d = rows.n_features
     eps10 = 10 * np.finfo(np.float64).eps
     nk, means = np.empty(k), np.empty((k, d))
     scatter = np.empty((k, d, d))                                             # sum_r w (x - mean)(x - mean)^T
     for c in range(k):
-        g = rows.moments(c, shift)
+        g = sh.sum(rows.moments(c, shift))
         a, b, n0 = g[:d, :d], g[d, :d], g[d, d]
         nk[c] = n0 + eps10
         mt = b / nk[c]
@@ -453,33 +454,35 @@ def _precision_cholesky(cov, covariance_type, k, d):
     return out, log_det
 
 
-def gmm_fit_predict(X, n_components, covariance_type="full", random_state=0, tol=1e-3, reg_covar=1e-6, max_iter=100):
+def gmm_fit_predict(X, n_components, covariance_type="full", random_state=0, tol=1e-3, reg_covar=1e-6, max_iter=100, comm=None):
     """``GaussianMixture(n_components, covariance_type=..., random_state=...).fit(X).predict(X)`` with scikit-learn's defaults
-    (k-means initialisation, one run): returns ``(labels int32 (N), n_iter, converged)``."""
+    (k-means initialisation, one run): returns ``(labels int32 (N), n_iter, converged)``.  With ``comm``: ``X`` is this rank's
+    block of rows and the mixture is that of the whole matrix (see ``kmeans_fit``): the ranks exchange the lower bound and
+    ``k`` weighted ``(D + 1) x (D + 1)`` moment matrices per EM iteration."""
     from sklearn.utils import check_random_state
     rows, own = _as_rows(X)
     try:
-        k, d, n = int(n_components), rows.n_features, rows.n_rows
+        sh = _Shards(rows, comm)
+        k, d, n = int(n_components), rows.n_features, sh.total
         if n < 2:
             raise ValueError(f"Found array with {n} sample(s) (shape=({n}, {d})) while a minimum of 2 is required by GaussianMixture.")
         if n < k:
             raise ValueError(f"Expected n_samples >= n_components but got n_components = {k}, n_samples = {n}")
         if k > 64:
             raise ValueError("at most 64 mixture components on the device")
-        sh = _Shards(rows)
         sh.check_finite()
         shift = sh.center()[0]
         rs = check_random_state(random_state)
-        kmeans_fit(rows, k, random_state=rs)                                 # _initialize_parameters, init_params='kmeans'
+        kmeans_fit(rows, k, random_state=rs, comm=comm)                      # _initialize_parameters, init_params='kmeans'
         rows.resp_from_labels(k)
-        weights, means, cov = _gaussian_parameters(rows, k, shift, reg_covar, covariance_type)
+        weights, means, cov = _gaussian_parameters(sh, k, shift, reg_covar, covariance_type)
         weights /= n
         prec, log_det = _precision_cholesky(cov, covariance_type, k, d)
         lower_bound, converged, n_iter = -np.inf, False, 0
         for n_iter in range(1, max_iter + 1):
             prev = lower_bound
-            lower_bound = rows.estep(prec, means, log_det, np.log(weights)) / n
-            weights, means, cov = _gaussian_parameters(rows, k, shift, reg_covar, covariance_type)
+            lower_bound = sh.sum(np.array([rows.estep(prec, means, log_det, np.log(weights))]))[0] / n
+            weights, means, cov = _gaussian_parameters(sh, k, shift, reg_covar, covariance_type)
             weights /= weights.sum()
             prec, log_det = _precision_cholesky(cov, covariance_type, k, d)
             if abs(lower_bound - prev) < tol:
@@ -496,8 +499,8 @@ def gmm_fit_predict(X, n_components, covariance_type="full", random_state=0, tol
             rows.close()
 
 
-def gmm_lbs(X, n, type="full", ramdom_state=0):
+def gmm_lbs(X, n, type="full", ramdom_state=0, comm=None):
     """Drop-in for ``mtflearn.clustering.gmm_lbs`` (reference ``_clustering_functions.py:25-33``; the keyword is spelt
-    ``ramdom_state`` there)."""
-    labels, _, _ = gmm_fit_predict(X, n, covariance_type=type, random_state=ramdom_state)
-    return _relabel_by_size(labels.astype(np.intp))                          # predict() = argmax: numpy's index type
+    ``ramdom_state`` there).  With ``comm``: ``X`` is this rank's block, the labels of the whole matrix are returned."""
+    labels, _, _ = gmm_fit_predict(X, n, covariance_type=type, random_state=ramdom_state, comm=comm)
+    return _relabel_by_size(gather_labels(labels, comm).astype(np.intp))     # predict() = argmax: numpy's index type

@@ -1,5 +1,5 @@
-"""Sharded k-means on CPU: world_size-2 and -3 gloo processes run the product's control flow (``mtflearn_amd.clustering.
-kmeans_fit`` / ``kmeans_lbs`` with ``comm=``) with the test-aid communicator ``TorchComm`` and a NumPy stand-in for the
+"""Sharded k-means / Gaussian mixture on CPU: world_size-2 and -3 gloo processes run the product's control flow (``mtflearn_amd.clustering.
+kmeans_fit`` / ``kmeans_lbs`` / ``gmm_fit_predict`` / ``gmm_lbs`` with ``comm=``) with the test-aid communicator ``TorchComm`` and a NumPy stand-in for the
 device passes (same methods as ``DeviceRows``, scikit-learn's formulas in NumPy).  Under test is everything around the kernels:
 the rank-ordered sums, the owner look-up of the seeding draws over block boundaries (ragged and empty blocks), fetching
 candidate rows from their owners, the label gather.  The result must be scikit-learn's clustering of the WHOLE matrix, and
@@ -72,6 +72,28 @@ class HostRows:
     def labels(self):
         return self._labels.copy()
 
+    # ---- mixture passes (sklearn/mixture/_gaussian_mixture.py formulas) ----
+    def resp_from_labels(self, k):
+        self.resp = np.zeros((self.n_rows, k))
+        self.resp[np.arange(self.n_rows), self._labels] = 1.0
+
+    def estep(self, prec_chol, means, log_det, log_w, want_resp=True):
+        from scipy.special import logsumexp
+        k, d = means.shape
+        lp = np.empty((self.n_rows, k))
+        for c in range(k):
+            y = self.X @ prec_chol[c] - means[c] @ prec_chol[c]
+            lp[:, c] = (-0.5 * (d * np.log(2 * np.pi) + np.sum(y * y, axis=1)) + log_det[c]) + log_w[c]
+        lse = logsumexp(lp, axis=1) if self.n_rows else np.zeros(0)
+        if want_resp:
+            self.resp = np.exp(lp - lse[:, None])
+        self._labels = lp.argmax(axis=1).astype(np.int32) if self.n_rows else np.zeros(0, dtype=np.int32)
+        return float(lse.sum())
+
+    def moments(self, component, shift):
+        z = np.concatenate([self.X - shift, np.ones((self.n_rows, 1))], axis=1)
+        return (z * self.resp[:, component][:, None]).T @ z
+
     def close(self):
         pass
 
@@ -120,13 +142,18 @@ def _worker(rank, world, port, tmpdir):
                 whole = C.gather_labels(labels, comm)
                 lbs = C.kmeans_lbs(HostRows(X[cuts[rank]:cuts[rank + 1]]), k, random_state=seed, comm=comm)
                 np.savez(os.path.join(tmpdir, f"{kind}_{k}_{seed}_{rank}.npz"), labels=whole, centers=centers, n_iter=n_iter, lbs=lbs)
+            for k, cov in ((3, "full"), (5, "diag"), (4, "tied"), (5, "spherical")):
+                mine, n_iter, conv = C.gmm_fit_predict(HostRows(X[cuts[rank]:cuts[rank + 1]]), k, covariance_type=cov, comm=comm)
+                lbs = C.gmm_lbs(HostRows(X[cuts[rank]:cuts[rank + 1]]), k, type=cov, comm=comm)
+                np.savez(os.path.join(tmpdir, f"gmm_{kind}_{k}_{cov}_{rank}.npz"), labels=C.gather_labels(mine, comm), n_iter=n_iter,
+                         converged=conv, lbs=lbs)
         comm.barrier()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_kmeans_is_the_clustering_of_the_whole_matrix(tmp_path, world):
+def test_sharded_clustering_is_the_clustering_of_the_whole_matrix(tmp_path, world):
     import torch.multiprocessing as mp
     from sklearn.cluster import KMeans
     from mtflearn_amd import clustering as C
@@ -147,6 +174,16 @@ def test_sharded_kmeans_is_the_clustering_of_the_whole_matrix(tmp_path, world):
                         np.testing.assert_allclose(f["centers"], model.cluster_centers_, rtol=0, atol=1e-9)
                         assert int(f["n_iter"]) == model.n_iter_
                         np.testing.assert_array_equal(f["lbs"], C._relabel_by_size(model.labels_))
+        from sklearn.mixture import GaussianMixture
+        for k, cov in ((3, "full"), (5, "diag"), (4, "tied"), (5, "spherical")):
+            model = GaussianMixture(k, covariance_type=cov, random_state=0).fit(X)
+            ref = model.predict(X)
+            for kind in ("even", "ragged", "empty"):
+                for rank in range(world):
+                    with np.load(tmp_path / f"gmm_{kind}_{k}_{cov}_{rank}.npz") as f:
+                        np.testing.assert_array_equal(f["labels"], ref, err_msg=f"gmm {kind} {k} {cov} rank {rank}")
+                        assert int(f["n_iter"]) == model.n_iter_ and bool(f["converged"]) == model.converged_
+                        np.testing.assert_array_equal(f["lbs"], C._relabel_by_size(ref.astype(np.intp)))
     finally:
         C._as_rows = saved
 
