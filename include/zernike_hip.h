@@ -377,6 +377,8 @@ int zk_gmm_estep(zk_rows* rows, const double* prec_chol, const double* means, co
                  int want_resp, double* lse_sum_out);
 int zk_gmm_resp_from_labels(zk_rows* rows, int k);               /* one-hot of the current labels */
 int zk_gmm_moments(zk_rows* rows, int component, const double* shift, double* gram_out);
+/* The same sums with unit weights (the Gram matrix about `shift` with the column sums and N: what a covariance needs). */
+int zk_rows_gram(zk_rows* rows, const double* shift, double* gram_out);
 
 /* Device memory for callers that have no allocator of their own (a NumPy / C user of the *_dev entry points). */
 int zk_device_malloc(int device, int64_t bytes, void** out_dev);

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ 
         }
       }
     }
-    for (int r = tid; r < 64; r += nthreads) wt[r] = r0 + r < N ? w[r0 + r] : 0.0;
+    for (int r = tid; r < 64; r += nthreads) wt[r] = r0 + r < N ? (w ? w[r0 + r] : 1.0) : 0.0;
     __syncthreads();
     if (worker) {
 #pragma unroll 2
@@ -1117,12 +1117,8 @@ extern "C" int zk_gmm_resp_from_labels(zk_rows* m, int k) {
   return 0;
 }
 
-// M-step sums of component c about `shift` (D): gram_out (D+1, D+1) = sum_r resp[c][r] [x_r - shift | 1]^T [x_r - shift | 1]
-// -- second moments, first moments in the last row / column, the component's weight in the corner.
-extern "C" int zk_gmm_moments(zk_rows* m, int c, const double* shift, double* gram_out) {
-  if (!m || !shift || !gram_out) return zk_fail(ZK_E_BADARG, "null pointer");
-  if (!m->d_resp || c < 0 || (size_t)(c + 1) * m->N * sizeof(double) > m->resp_bytes) return zk_fail(ZK_E_BADARG, "no such component");
-  ZK_ON_DEVICE(m->device);
+// sum_r w_r [x_r - shift | 1]^T [x_r - shift | 1] with w = one plane of the responsibilities, or 1 (w_dev null)
+static int rows_gram(zk_rows* m, const double* w_dev, const double* shift, double* gram_out) {
   const int D = m->D, D1 = D + 1, T = (D1 + 3) / 4, n_ut = T * (T + 1) / 2;
   m->h_buf.assign(shift, shift + D);
   int rc = upload_tab(m, m->h_buf);
@@ -1137,8 +1133,23 @@ extern "C" int zk_gmm_moments(zk_rows* m, int c, const double* shift, double* gr
   if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)blocks * G * D1 * D1 * sizeof(double)))) return rc;
   if ((rc = allow_lds(wgram_kernel, lds))) return rc;
   hipLaunchKernelGGL(wgram_kernel, dim3((unsigned)blocks), dim3(threads), lds, m->stream, m->X, (long long)m->N, D, T, G,
-                     (const double*)m->d_tab, (const double*)m->d_resp + (size_t)c * m->N, (double*)m->d_part);
+                     (const double*)m->d_tab, w_dev, (double*)m->d_part);
   ZK_HIP(hipGetLastError());
-  blocks *= G;
-  return reduce_to_host(m, (int)blocks, D1 * D1, gram_out);
+  return reduce_to_host(m, (int)(blocks * G), D1 * D1, gram_out);
+}
+
+// M-step sums of component c about `shift` (D): gram_out (D+1, D+1) = sum_r resp[c][r] [x_r - shift | 1]^T [x_r - shift | 1]
+// -- second moments, first moments in the last row / column, the component's weight in the corner.
+extern "C" int zk_gmm_moments(zk_rows* m, int c, const double* shift, double* gram_out) {
+  if (!m || !shift || !gram_out) return zk_fail(ZK_E_BADARG, "null pointer");
+  if (!m->d_resp || c < 0 || (size_t)(c + 1) * m->N * sizeof(double) > m->resp_bytes) return zk_fail(ZK_E_BADARG, "no such component");
+  ZK_ON_DEVICE(m->device);
+  return rows_gram(m, (const double*)m->d_resp + (size_t)c * m->N, shift, gram_out);
+}
+
+// The same sums with unit weights: everything a covariance needs (pca), in a fixed summation order.
+extern "C" int zk_rows_gram(zk_rows* m, const double* shift, double* gram_out) {
+  if (!m || !shift || !gram_out) return zk_fail(ZK_E_BADARG, "null pointer");
+  ZK_ON_DEVICE(m->device);
+  return rows_gram(m, nullptr, shift, gram_out);
 }

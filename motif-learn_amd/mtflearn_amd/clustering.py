@@ -152,6 +152,52 @@ class DeviceRows:
         return out
 
 
+    def gram(self, shift):
+        """``sum_r [x_r - shift | 1]^T [x_r - shift | 1]`` (D+1, D+1), fixed summation order."""
+        shift = np.ascontiguousarray(shift, dtype=np.float64)
+        d1 = self.n_features + 1
+        out = np.empty((d1, d1))
+        _native.check(self._lib.zk_rows_gram(self._h, _p(shift), _p(out)), "zk_rows_gram")
+        return out
+
+    def project(self, mean, components):
+        """``(X - mean) components^T`` -> (n_rows, k) on the host (page-locked); the matrix stays on the device."""
+        lib, dev, n, d = self._lib, self.device, self.n_rows, self.n_features
+        components = np.ascontiguousarray(components, dtype=np.float64)
+        k = len(components)
+        out = _native.pinned.empty((n, k))
+        if n == 0:
+            return out
+        x_dev, bufs = lib.zk_rows_data(self._h), []
+
+        def to_device(arr):
+            arr = np.ascontiguousarray(arr, dtype=np.float64)
+            ptr = c_void_p()
+            _native.check(lib.zk_device_malloc(dev, arr.nbytes, byref(ptr)), "zk_device_malloc")
+            bufs.append(ptr)
+            _native.check(lib.zk_device_copy(dev, ptr, arr.ctypes.data_as(c_void_p), arr.nbytes, 1), "zk_device_copy")
+            return ptr
+
+        try:
+            d_mean = to_device(mean)
+            d_y = c_void_p()
+            _native.check(lib.zk_device_malloc(dev, n * min(k, 16) * 8, byref(d_y)), "zk_device_malloc")
+            bufs.append(d_y)
+            for done in range(0, k, 16):                                     # at most 16 components per launch
+                kk = min(16, k - done)
+                d_comp = to_device(components[done:done + kk])
+                _native.check(lib.zk_project_dev(dev, c_void_p(x_dev), n, d, d_mean, d_comp, kk, d_y, None), "zk_project_dev")
+                part = out if kk == k else np.empty((n, kk))
+                _native.check(lib.zk_device_synchronize(dev), "zk_device_synchronize")
+                _native.check(lib.zk_device_copy(dev, part.ctypes.data_as(c_void_p), d_y, part.nbytes, 2), "zk_device_copy")
+                if part is not out:
+                    out[:, done:done + kk] = part
+        finally:
+            for ptr in bufs:
+                lib.zk_device_free(dev, ptr)
+        return out
+
+
 def _as_rows(X):
     return (X, False) if isinstance(X, DeviceRows) else (DeviceRows(X), True)
 

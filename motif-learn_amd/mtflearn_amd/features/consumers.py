@@ -43,8 +43,35 @@ def _covariance_eigh(gram, n_rows):
     return mean, vt, eigenvals
 
 
-def pca(X, n_components=2, reconstruct=False):
-    """First ``n_components`` principal-component scores of ``X`` (N, D) -> (N, n_components) float64."""
+def _pca_resident(rows, n_components, comm):
+    """``pca`` of a matrix that is already on the device (``clustering.DeviceRows``), or of one spread over the ranks of a
+    communicator: the Gram matrix about the column means (``zk_rows_gram``, summed over the ranks in rank order), ``eigh``,
+    and the projection of this rank's rows.  Same ``covariance_eigh`` arithmetic as below up to the centring of the sums."""
+    from ..clustering import _Shards
+    sh = _Shards(rows, comm)
+    n, d = sh.total, rows.n_features
+    k = min(n, d) if n_components is None else n_components
+    if not isinstance(k, (int, np.integer)) or not 1 <= k <= min(n, d):
+        raise ValueError(f"n_components={n_components!r} must be between 1 and min(n_samples, n_features)={min(n, d)}")
+    if n < 2:
+        raise ValueError("PCA needs at least two samples")
+    shift = sh.sum(rows.colsum()) / n
+    mean, vt, _ = _covariance_eigh(sh.sum(rows.gram(shift)), n)
+    return rows.project(mean + shift, vt[:k])
+
+
+def pca(X, n_components=2, reconstruct=False, comm=None):
+    """First ``n_components`` principal-component scores of ``X`` (N, D) -> (N, n_components) float64.
+
+    ``X`` may be a ``mtflearn_amd.clustering.DeviceRows`` (a matrix already resident on the GPU); with ``comm`` it is this
+    rank's block of rows of a matrix spread over the ranks and the components are those of the whole matrix (the ranks
+    exchange one ``(D + 1) x (D + 1)`` Gram matrix); the scores of this rank's rows are returned."""
+    from ..clustering import DeviceRows
+    if isinstance(X, DeviceRows) or (hasattr(X, "gram") and hasattr(X, "project")):   # (tests plug a NumPy stand-in here)
+        return _pca_resident(X, n_components, comm)
+    if comm is not None and comm.world > 1:
+        with DeviceRows(X) as rows:
+            return _pca_resident(rows, n_components, comm)
     X = np.ascontiguousarray(X, dtype=np.float64)
     if X.ndim != 2:
         raise ValueError(f"Expected 2D array, got {X.ndim}D array instead")

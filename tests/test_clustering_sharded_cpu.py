@@ -90,6 +90,13 @@ class HostRows:
         self._labels = lp.argmax(axis=1).astype(np.int32) if self.n_rows else np.zeros(0, dtype=np.int32)
         return float(lse.sum())
 
+    def gram(self, shift):
+        z = np.concatenate([self.X - shift, np.ones((self.n_rows, 1))], axis=1)
+        return z.T @ z
+
+    def project(self, mean, components):
+        return (self.X - mean) @ np.asarray(components).T
+
     def moments(self, component, shift):
         z = np.concatenate([self.X - shift, np.ones((self.n_rows, 1))], axis=1)
         return (z * self.resp[:, component][:, None]).T @ z
@@ -142,6 +149,9 @@ def _worker(rank, world, port, tmpdir):
                 whole = C.gather_labels(labels, comm)
                 lbs = C.kmeans_lbs(HostRows(X[cuts[rank]:cuts[rank + 1]]), k, random_state=seed, comm=comm)
                 np.savez(os.path.join(tmpdir, f"{kind}_{k}_{seed}_{rank}.npz"), labels=whole, centers=centers, n_iter=n_iter, lbs=lbs)
+            from mtflearn_amd.features import pca
+            scores = pca(HostRows(X[cuts[rank]:cuts[rank + 1]]), 3, comm=comm)
+            np.save(os.path.join(tmpdir, f"pca_{kind}_{rank}.npy"), scores)
             for k, cov in ((3, "full"), (5, "diag"), (4, "tied"), (5, "spherical")):
                 mine, n_iter, conv = C.gmm_fit_predict(HostRows(X[cuts[rank]:cuts[rank + 1]]), k, covariance_type=cov, comm=comm)
                 lbs = C.gmm_lbs(HostRows(X[cuts[rank]:cuts[rank + 1]]), k, type=cov, comm=comm)
@@ -174,6 +184,12 @@ def test_sharded_clustering_is_the_clustering_of_the_whole_matrix(tmp_path, worl
                         np.testing.assert_allclose(f["centers"], model.cluster_centers_, rtol=0, atol=1e-9)
                         assert int(f["n_iter"]) == model.n_iter_
                         np.testing.assert_array_equal(f["lbs"], C._relabel_by_size(model.labels_))
+        from sklearn.decomposition import PCA
+        ref_scores = PCA(n_components=3).fit_transform(X)
+        for kind in ("even", "ragged", "empty"):
+            cuts = _blocks(len(X), world, kind)
+            got = np.concatenate([np.load(tmp_path / f"pca_{kind}_{rank}.npy") for rank in range(world)])
+            np.testing.assert_allclose(got, ref_scores, rtol=0, atol=1e-10 * np.abs(ref_scores).max())
         from sklearn.mixture import GaussianMixture
         for k, cov in ((3, "full"), (5, "diag"), (4, "tied"), (5, "spherical")):
             model = GaussianMixture(k, covariance_type=cov, random_state=0).fit(X)

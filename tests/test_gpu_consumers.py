@@ -145,3 +145,18 @@ def test_kmeans_on_the_matrix_where_the_batch_kernel_left_it():
         finally:
             comm.close()
     assert torch.isfinite(moments).all()                         # an adopted matrix is borrowed, not freed
+
+
+def test_pca_of_a_resident_matrix():
+    """pca(DeviceRows): Gram matrix in a fixed order (zk_rows_gram) + projection, the matrix staying where it is."""
+    from sklearn.decomposition import PCA
+    from mtflearn_amd.features import pca
+    from mtflearn_amd.clustering import DeviceRows, kmeans_fit
+    X = _moment_matrix()
+    with DeviceRows(X) as rows:
+        for k in (2, 20, 45):
+            ref = PCA(n_components=k).fit_transform(X)
+            got = pca(rows, n_components=k)
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+        np.testing.assert_array_equal(pca(rows, 3), pca(rows, 3))              # bit-identical from run to run
+        kmeans_fit(rows, 3)                                                     # and the same resident matrix clusters on
