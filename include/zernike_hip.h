@@ -380,6 +380,23 @@ int zk_gmm_moments(zk_rows* rows, int component, const double* shift, double* gr
 /* The same sums with unit weights (the Gram matrix about `shift` with the column sums and N: what a covariance needs). */
 int zk_rows_gram(zk_rows* rows, const double* shift, double* gram_out);
 
+/* ------------------------------------------------------------------------------------------------------
+ * The manifold consumer: ForceGraph8, reference manifold/force_relaxed.py:285-366 (csrc/zk_graph.hip).
+ *   zk_rows_knn_correlation  compute_graph's neighbour search (:67-74: sklearn NearestNeighbors(metric='correlation'), brute
+ *                            force) on the resident matrix: ind_out / dist_out (N, k), self first, sorted by distance; with
+ *                            P_out also calculate_asymmetric_Pij (:17-52) for the given local_connectivity / perplexity.
+ *   zk_force_layout_stage    optimize_stage (:236-266), the strictly sequential force-directed sweep over the graph's pairs
+ *                            with its tau_rand_int negative sampling: HOST code here as in the reference (numba), operation
+ *                            for operation; xy (n_nodes, 2) and rng_state (3) are updated in place, log_out (optional) receives
+ *                            xy after every sweep.  force_params = (N, M, alpha, beta).
+ * ------------------------------------------------------------------------------------------------------ */
+int zk_rows_knn_correlation(zk_rows* rows, int n_neighbors, int local_connectivity, double perplexity, int64_t* ind_out,
+                            double* dist_out, double* P_out);
+int zk_force_layout_stage(double* xy, int64_t n_nodes, const int64_t* node1, const int64_t* node2, const double* weight,
+                          int64_t n_pairs, const int64_t* nbrs_ind, int n_neighbors, int64_t num_iterations,
+                          const double* force_params, int num_negative_samples, double learning_rate, int64_t* rng_state,
+                          double* log_out);
+
 /* Device memory for callers that have no allocator of their own (a NumPy / C user of the *_dev entry points). */
 int zk_device_malloc(int device, int64_t bytes, void** out_dev);
 int zk_device_free(int device, void* dev);

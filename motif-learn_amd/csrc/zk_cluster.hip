@@ -760,6 +760,16 @@ extern "C" int zk_rows_create(int device, const double* X_host, int64_t N, int D
 
 extern "C" const double* zk_rows_data(const zk_rows* m) { return m ? m->X : nullptr; }
 
+// for the other consumers of a resident matrix (zk_graph.hip)
+int zk_rows_shape(const zk_rows* m, int* device, int64_t* n_rows, int* n_features, void** stream) {
+  if (!m) return zk_fail(ZK_E_BADARG, "null matrix");
+  *device = m->device;
+  *n_rows = m->N;
+  *n_features = m->D;
+  *stream = (void*)m->stream;
+  return 0;
+}
+
 // Column sums of the matrix (first pass of numpy.mean).
 extern "C" int zk_rows_colsum(zk_rows* m, double* sums_out) {
   if (!m || !sums_out) return zk_fail(ZK_E_BADARG, "null pointer");

@@ -109,6 +109,10 @@ SYMBOLS = {
     "zk_gmm_resp_from_labels": (c_int, [c_void_p, c_int]),
     "zk_gmm_moments": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_double)]),
     "zk_rows_gram": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
+    "zk_rows_knn_correlation": (c_int, [c_void_p, c_int, c_int, c_double, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
+    "zk_force_layout_stage": (c_int, [POINTER(c_double), c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_double), c_int64,
+                                      POINTER(c_int64), c_int, c_int64, POINTER(c_double), c_int, c_double, POINTER(c_int64),
+                                      POINTER(c_double)]),
     "zk_device_malloc": (c_int, [c_int, c_int64, POINTER(c_void_p)]),
     "zk_device_free": (c_int, [c_int, c_void_p]),
     "zk_device_copy": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int]),
