@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256) void unit_rows_kernel(const double* __restrict
 // coordinates are wave-uniform scalar operands (Zt); every lane keeps its K best (distance, index) pairs sorted in registers.
 // A candidate enters the insertion code only when some lane of the wave wants it (after the first few hundred candidates
 // almost none does).  Ties keep the smaller index first.
+// (Tried: the one-step-ahead scalar-operand pipelining of the mixture E step with 16-candidate blocks -- 85 -> 136 ms per
+//  100 000 x 45: the candidate table is a 36-MB stream, each request pays an L2 round trip and one wave cannot keep enough of
+//  them in flight in its SGPRs; the compiler's four-loads-then-wait schedule of this form is better.  More waves per query
+//  tile would be the next step; the optimiser that follows costs 100x this search, so it was not taken.)
 template <int K>
 __global__ __launch_bounds__(64) void knn_kernel(const double* __restrict__ Z, const double* __restrict__ Zt, long long N, int D,
                                                  long long Np, int k, long long* __restrict__ ind, double* __restrict__ dist) {
