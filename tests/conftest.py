@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "motif-learn_amd")):
+for p in (ROOT, os.path.join(ROOT, "motif-learn_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 

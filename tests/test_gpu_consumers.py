@@ -160,3 +160,76 @@ def test_pca_of_a_resident_matrix():
             np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
         np.testing.assert_array_equal(pca(rows, 3), pca(rows, 3))              # bit-identical from run to run
         kmeans_fit(rows, 3)                                                     # and the same resident matrix clusters on
+
+
+def test_row_passes_on_edge_shapes():
+    """Every pass of csrc/zk_cluster.hip against its NumPy statement (the stand-in of tests/test_clustering_sharded_cpu.py) on
+    the shapes where tiling can go wrong: 1 to 127 features (odd, even, exactly 64), row counts below / at / just past a
+    64-row tile, one cluster to more than the register-resident limit, ragged last tiles."""
+    from scipy import linalg
+    from test_clustering_sharded_cpu import HostRows
+    from mtflearn_amd.clustering import DeviceRows
+    rng = np.random.default_rng(99)
+    shapes = [(1, 1), (2, 1), (63, 2), (64, 3), (65, 64), (129, 127), (1000, 45), (4097, 66), (200, 91), (777, 5), (5000, 120),
+              (64 * 7, 33), (64 * 7 + 1, 80), (64 * 7 - 1, 81)]
+    for n, d in shapes:
+        X = rng.standard_normal((n, d)) * (1 + rng.random(d)) + rng.standard_normal(d) * 3
+        host = HostRows(X)
+        with DeviceRows(X) as dev:
+            np.testing.assert_allclose(dev.colsum(), host.colsum(), rtol=1e-12, atol=1e-9)
+            mean = host.colsum() / n
+            sq_d, bad_d = dev.center_at(mean)
+            sq_h, bad_h = host.center_at(mean)
+            np.testing.assert_allclose(sq_d, sq_h, rtol=1e-12, atol=1e-12)
+            assert bad_d == bad_h == 0
+            idx = rng.integers(0, n, min(n, 5))
+            np.testing.assert_array_equal(dev.fetch(idx), host.fetch(idx))
+            for t in (1, 4, 7):
+                cand = host.fetch(rng.integers(0, n, t))
+                csq = np.einsum("ij,ij->i", cand, cand)
+                np.testing.assert_allclose(dev.seed_step(cand, csq, False), host.seed_step(cand, csq, False), rtol=1e-11, atol=1e-9)
+                which = int(rng.integers(0, t))
+                vals = np.sort(rng.random(3)) * host._cand[which].sum()
+                pick_d, pick_h = dev.seed_pick(which, vals), host.seed_pick(which, vals)
+                near = np.abs(np.cumsum(host.closest)[pick_h] - vals) < 1e-9 * max(1.0, host.closest.sum())
+                assert np.all((pick_d == pick_h) | near)
+                np.testing.assert_allclose(dev.seed_step(cand, csq, True), host.seed_step(cand, csq, True), rtol=1e-11, atol=1e-9)
+            for k in (1, 3, 8, 13, 16, 17, 40):
+                if k > n:
+                    continue
+                centers = host.fetch(rng.choice(n, k, replace=False)) + 0.01 * rng.standard_normal((k, d))
+                dev.reset_labels(), host.reset_labels()
+                for update in (True, False):
+                    s_d, c_d, ch_d = dev.lloyd(centers, update)
+                    s_h, c_h, ch_h = host.lloyd(centers, update)
+                    np.testing.assert_array_equal(dev.labels(), host.labels())
+                    assert ch_d == ch_h
+                    if update:
+                        np.testing.assert_array_equal(c_d, c_h)
+                        np.testing.assert_allclose(s_d, s_h, rtol=1e-11, atol=1e-10)
+                np.testing.assert_allclose(dev.own_distance(centers), host.own_distance(centers), rtol=1e-11, atol=1e-12)
+            for k in (1, 2, 5, 12):
+                if k > n or d > 91 and k > 5:
+                    continue
+                means = X[rng.choice(n, k, replace=False)]
+                prec = np.zeros((k, d, d))
+                for c in range(k):
+                    a = rng.standard_normal((d, d)) * 0.3 + np.eye(d) * 2
+                    prec[c] = linalg.solve_triangular(linalg.cholesky(a @ a.T, lower=True), np.eye(d), lower=True).T
+                log_det = np.log(np.einsum("kii->ki", prec)).sum(axis=1)
+                log_w = np.log(np.full(k, 1.0 / k))
+                lse_d, lse_h = dev.estep(prec, means, log_det, log_w), host.estep(prec, means, log_det, log_w)
+                assert abs(lse_d - lse_h) <= 1e-10 * max(1.0, abs(lse_h))
+                agree = np.mean(dev.labels() == host.labels())
+                assert agree == 1.0 or (agree > 0.99 and n > 500)
+                shift = X.mean(axis=0)
+                for c in range(k):
+                    g_h = host.moments(c, shift)
+                    np.testing.assert_allclose(dev.moments(c, shift), g_h, rtol=1e-10, atol=1e-10 * np.abs(g_h).max())
+                dev.lloyd(means - mean, False), host.lloyd(means - mean, False)
+                dev.resp_from_labels(k), host.resp_from_labels(k)
+                np.testing.assert_allclose(dev.moments(0, shift), host.moments(0, shift), rtol=1e-11, atol=1e-9)
+            g_h = host.gram(mean)
+            np.testing.assert_allclose(dev.gram(mean), g_h, rtol=1e-11, atol=1e-11 * np.abs(g_h).max())
+            comp = rng.standard_normal((min(d, 20), d))
+            np.testing.assert_allclose(dev.project(mean, comp), host.project(mean, comp), rtol=1e-11, atol=1e-11)
