@@ -627,8 +627,14 @@ __global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ 
 }
 
 // ---- host helpers ------------------------------------------------------------------------------------------------
-// two tile buffers (the next tile's DMA under this tile's arithmetic) while three waves still fit a CU's 160 KiB, else one
-int tile_bufs(const zk_rows* m, size_t extra = 0) { return 3 * ((size_t)2 * TILE * m->D * sizeof(double) + extra + 512) <= 160 * 1024 ? 2 : 1; }
+// Waves per CU matter more than overlap inside a wave (4 M x 45, two buffers / 3 waves -> one buffer / 6 waves per CU: Lloyd
+// pass with sums 0.67 -> 0.46 ms, labels only 0.45 -> 0.31, seeding 0.41 -> 0.36): two tile buffers (the next tile's DMA under
+// this tile's arithmetic) only while eight waves still fit a CU's 160 KiB, else one
+int tile_bufs(const zk_rows* m, size_t extra = 0) {
+  static const int forced = getenv("ZK_TILE_NBUF") ? atoi(getenv("ZK_TILE_NBUF")) : 0;  // experiments
+  if (forced == 1 || forced == 2) return forced;
+  return 8 * ((size_t)2 * TILE * m->D * sizeof(double) + extra + 512) <= 160 * 1024 ? 2 : 1;
+}
 size_t tile_lds(const zk_rows* m, int nbuf) { return (size_t)nbuf * TILE * m->D * sizeof(double); }
 
 // persistent single-wave workgroups: as many per CU as the LDS tile allows (at most 8), never more than tiles
