@@ -132,3 +132,29 @@ def test_symmetry_maps_full_4096():
         start, count, _ = shard_bounds(H, rank, 8)
         frame_maps_device(plan, f, n_c, folds=(2, 3, 4, 6), theta=theta, row0=start, n_rows=count, full=full)
     assert torch.equal(full[0], rot) and torch.equal(full[1], ab) and torch.equal(full[2], mir)
+
+
+def test_clustering_of_the_full_moment_matrix():
+    """BASELINE configs[1] carried to its consumer: all 4 068 289 dense 32-px windows of a 2048^2 frame -> moments (device
+    resident) -> k-means.  Against scikit-learn's KMeans on the same matrix copied to the host (what the reference's
+    ``kmeans_lbs`` computes, ``clustering/_clustering_functions.py:8-22``): tens of Lloyd iterations at the full size."""
+    import torch
+    from sklearn.cluster import KMeans
+    from mtflearn_amd import distributed as D
+    from mtflearn_amd.clustering import DeviceRows, kmeans_fit, _relabel_by_size
+    from mtflearn_amd.synthetic import honeycomb_frame
+    frame = torch.from_numpy(honeycomb_frame(2048, seed=0)).cuda()
+    patches = frame.unfold(0, 32, 1).unfold(1, 32, 1).reshape(-1, 32, 32).contiguous()
+    plan = _zps(8, 32)._device_plan()
+    moments = D.patch_moments_device(plan, patches)
+    torch.cuda.synchronize()
+    del patches
+    assert moments.shape == (4068289, 45)
+    with DeviceRows.adopt(moments.data_ptr(), moments.shape[0], moments.shape[1], device=0) as rows:
+        labels, centers, n_iter = kmeans_fit(rows, 4, random_state=0)
+    ref = KMeans(n_clusters=4, random_state=0).fit(moments.cpu().numpy())
+    assert n_iter == ref.n_iter_ and n_iter > 5
+    assert np.mean(labels == ref.labels_) >= 0.999999                       # ties at the last bit: at most a handful of 4 M rows
+    np.testing.assert_allclose(centers, ref.cluster_centers_, rtol=0, atol=1e-9 * np.abs(ref.cluster_centers_).max())
+    sizes = np.bincount(_relabel_by_size(labels))
+    assert (np.diff(sizes) <= 0).all() and sizes.sum() == 4068289
