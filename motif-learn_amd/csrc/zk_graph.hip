@@ -55,16 +55,20 @@ __global__ __launch_bounds__(256) void unit_rows_kernel(const double* __restrict
 // almost none does).  Ties keep the smaller index first.
 // (Tried: the one-step-ahead scalar-operand pipelining of the mixture E step with 16-candidate blocks -- 85 -> 136 ms per
 //  100 000 x 45: the candidate table is a 36-MB stream, each request pays an L2 round trip and one wave cannot keep enough of
-//  them in flight in its SGPRs; the compiler's four-loads-then-wait schedule of this form is better.  More waves per query
-//  tile would be the next step; the optimiser that follows costs 100x this search, so it was not taken.)
-template <int K>
-__global__ __launch_bounds__(64) void knn_kernel(const double* __restrict__ Z, const double* __restrict__ Zt, long long N, int D,
-                                                 long long Np, int k, long long* __restrict__ ind, double* __restrict__ dist) {
-  extern __shared__ __attribute__((aligned(16))) double tile[];  // [64][D]
-  const int lane = threadIdx.x;
+//  them in flight in its SGPRs; the compiler's four-loads-then-wait schedule of this form is better.)
+// WAVES waves share the query tile and split the candidates into WAVES consecutive ranges (more waves per CU: the candidate
+// table is a stream through the scalar data path and one wave per 23-KiB tile cannot hide its latency -- 100 000 x 45, k = 10:
+// 85 ms with one wave per tile); afterwards the waves hand their lists to wave 0 through LDS, one at a time in range order, and
+// wave 0 inserts them (ranges ascend, so ties still keep the smaller index first).
+template <int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void knn_kernel(const double* __restrict__ Z, const double* __restrict__ Zt, long long N, int D,
+                                                         long long Np, int k, long long* __restrict__ ind, double* __restrict__ dist) {
+  extern __shared__ __attribute__((aligned(16))) double tile[];  // [64][D], then the hand-over area [k][64] x (double, int64)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long q0 = (long long)blockIdx.x * 64;
   const long long total = N * D;
-  for (int e = lane; e < 64 * D; e += 64) tile[e] = q0 * D + e < total ? Z[q0 * D + e] : 0.0;
+  for (int e = threadIdx.x; e < 64 * D; e += 64 * WAVES) tile[e] = q0 * D + e < total ? Z[q0 * D + e] : 0.0;
   __syncthreads();
   const double* row = tile + lane * D;
   double bd[K];
@@ -72,8 +76,25 @@ __global__ __launch_bounds__(64) void knn_kernel(const double* __restrict__ Z, c
 #pragma unroll
   for (int p = 0; p < K; ++p) bd[p] = std::numeric_limits<double>::infinity(), bi[p] = -1;
   double worst = std::numeric_limits<double>::infinity();
+  auto insert = [&](double cd, long long ci) {
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+      const bool lt = cd < bd[p];
+      const double td = bd[p];
+      const long long ti = bi[p];
+      bd[p] = lt ? cd : td;
+      bi[p] = lt ? ci : ti;
+      cd = lt ? td : cd;
+      ci = lt ? ti : ci;
+    }
+#pragma unroll
+    for (int p = 0; p < K; ++p)
+      if (p == k - 1) worst = bd[p];
+  };
   const ZK_CONST double* zt = zk_const(Zt);
-  for (long long j0 = 0; j0 < Np; j0 += 8) {
+  const long long span = ((Np / 8 + WAVES - 1) / WAVES) * 8;  // candidates per wave, a multiple of eight
+  const long long j_lo = wave * span, j_hi = j_lo + span < Np ? j_lo + span : Np;
+  for (long long j0 = j_lo; j0 < j_hi; j0 += 8) {
     double acc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = 0.0;
@@ -87,24 +108,29 @@ __global__ __launch_bounds__(64) void knn_kernel(const double* __restrict__ Z, c
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const long long j = j0 + c;
-      double cd = 1.0 - acc[c];
-      if (j < N && __ballot(cd < worst)) {
-        long long ci = j;
+      const double cd = 1.0 - acc[c];
+      if (j < N && __ballot(cd < worst)) insert(cd, j);
+    }
+  }
+  if constexpr (WAVES > 1) {
+    double* hd = tile + 64 * D;
+    long long* hi = (long long*)(hd + K * 64);
+    for (int w = 1; w < WAVES; ++w) {
+      __syncthreads();  // the hand-over area is free (and, the first time, every wave has finished its scan)
+      if (wave == w) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) hd[p * 64 + lane] = bd[p], hi[p * 64 + lane] = bi[p];
+      }
+      __syncthreads();
+      if (wave == 0) {
 #pragma unroll
         for (int p = 0; p < K; ++p) {
-          const bool lt = cd < bd[p];
-          const double td = bd[p];
-          const long long ti = bi[p];
-          bd[p] = lt ? cd : td;
-          bi[p] = lt ? ci : ti;
-          cd = lt ? td : cd;
-          ci = lt ? ti : ci;
+          const double cd = hd[p * 64 + lane];
+          if (p < k && __ballot(cd < worst)) insert(cd, hi[p * 64 + lane]);
         }
-#pragma unroll
-        for (int p = 0; p < K; ++p)
-          if (p == k - 1) worst = bd[p];
       }
     }
+    if (wave != 0) return;
   }
   const long long q = q0 + lane;
   if (q < N) {
@@ -169,7 +195,7 @@ extern "C" int zk_rows_knn_correlation(zk_rows* m, int k, int local_connectivity
   if (rc) return rc;
   if (k < 1 || k > 64 || k > N) return zk_fail(ZK_E_BADARG, "need 1 <= n_neighbors <= min(64, n_samples)");
   if (P_out && (local_connectivity < 0 || local_connectivity >= k || !(perplexity > 0.0))) return zk_fail(ZK_E_BADARG, "bad affinity parameters");
-  if ((size_t)64 * D * sizeof(double) > 64 * 1024) return zk_fail(ZK_E_BADARG, "too many features for the query tile");
+  if ((size_t)64 * D * sizeof(double) + 16 * 64 * 16 > 64 * 1024) return zk_fail(ZK_E_BADARG, "too many features for the query tile");
   ZK_ON_DEVICE(device);
   hipStream_t s = (hipStream_t)stream_v;
   const long long Np = (N + 7) & ~7LL;
@@ -192,11 +218,11 @@ extern "C" int zk_rows_knn_correlation(zk_rows* m, int k, int local_connectivity
   const size_t lds = (size_t)64 * D * sizeof(double);
   const unsigned grid = (unsigned)((N + 63) / 64);
   if (k <= 16)
-    hipLaunchKernelGGL(knn_kernel<16>, dim3(grid), dim3(64), lds, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
+    hipLaunchKernelGGL((knn_kernel<16, 4>), dim3(grid), dim3(256), lds + (size_t)16 * 64 * 16, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
   else if (k <= 32)
-    hipLaunchKernelGGL(knn_kernel<32>, dim3(grid), dim3(64), lds, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
+    hipLaunchKernelGGL((knn_kernel<32, 1>), dim3(grid), dim3(64), lds, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
   else
-    hipLaunchKernelGGL(knn_kernel<64>, dim3(grid), dim3(64), lds, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
+    hipLaunchKernelGGL((knn_kernel<64, 1>), dim3(grid), dim3(64), lds, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
   if (P_out)
     hipLaunchKernelGGL(affinity_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_dist, (long long)N, k, local_connectivity,
                        std::log2(perplexity), d_P);
