@@ -27,7 +27,8 @@ import numpy as np
 from . import _native
 from .features.pickers import _device
 
-__all__ = ["kmeans_lbs", "gmm_lbs", "sort_lbs", "DeviceRows", "kmeans_fit", "gmm_fit_predict", "gather_labels"]
+__all__ = ["kmeans_lbs", "gmm_lbs", "sort_lbs", "seg_lbs", "normalize_xy", "DeviceRows", "kmeans_fit", "gmm_fit_predict",
+           "gather_labels"]
 
 _PD = POINTER(c_double)
 
@@ -435,6 +436,36 @@ def sort_lbs(lbs):
     unique_lbs = unique_lbs[np.argsort(counts)[::-1]]
     lut = dict(zip(unique_lbs.tolist(), range(len(unique_lbs))))
     return np.vectorize(lut.get)(lbs)
+
+
+def normalize_xy(xy, low=0, high=1):
+    """``mtflearn.clustering.normalize_xy`` (reference ``_clustering_functions.py:46-50``)."""
+    vmax = xy.max()
+    vmin = xy.min()
+    return (xy - vmin) / (vmax - vmin) * (high - low) + low
+
+
+def seg_lbs(xy, size=256, t=0.01):
+    """``mtflearn.clustering.seg_lbs`` (reference ``_clustering_functions.py:52-64``): the points of a 2-D layout (e.g.
+    ``ForceGraph8``'s) rasterised into a ``size`` x ``size`` image, dilated by a radius-3 disk, segmented into connected
+    components, labels renumbered by decreasing size.  A few thousand pixel operations: host code.  The reference calls
+    scikit-image's ``dilation(aa, disk(3))`` and ``label(aa)`` (absent from this image); the same operations are taken from
+    SciPy here -- grey dilation with the ``x^2 + y^2 <= 9`` footprint, 8-connected components numbered in raster order.
+    Parity unpinned (nothing of scikit-image can run here)."""
+    from scipy import ndimage as ndi
+    xy_norm = normalize_xy(xy, -size * 0.9 // 2, size * 0.9 // 2) + size // 2
+    xy_ = np.round(xy_norm).astype(int)
+    x, y = xy_.T
+    aa = np.zeros((size, size))
+    s = 3
+    aa[y, x] = 1
+    grid = np.arange(-s, s + 1)
+    disk = (grid[:, None] ** 2 + grid[None, :] ** 2 <= s * s)
+    aa = ndi.grey_dilation(aa, footprint=disk, mode="constant", cval=0.0)
+    lbs_img, _ = ndi.label(aa, structure=np.ones((3, 3)))
+    lbs = lbs_img[y, x]
+    lbs = lbs - lbs.min()
+    return sort_lbs(lbs)
 
 
 # ------------------------------------------------------------------------------------------------- Gaussian mixture

@@ -41,3 +41,17 @@ def test_no_gpu_means_an_error_not_a_fallback(golden):
         pytest.skip("a HIP device is visible")
     with pytest.raises(RuntimeError, match="no HIP device"):
         kmeans_lbs(golden["Xa"], 4)
+
+
+def test_seg_lbs_segments_a_layout():
+    """``seg_lbs`` (host only): three well-separated point clouds of different sizes come back as labels 0, 1, 2 by size."""
+    from mtflearn_amd.clustering import seg_lbs, normalize_xy
+    rng = np.random.default_rng(0)
+    sizes = (300, 150, 60)
+    xy = np.concatenate([rng.standard_normal((n, 2)) * 0.4 + c for n, c in zip(sizes, ((0, 0), (8, 1), (3, 9)))])
+    lbs = seg_lbs(xy)
+    start = 0
+    for want, n in enumerate(sizes):
+        assert (lbs[start:start + n] == want).mean() > 0.9
+        start += n
+    np.testing.assert_allclose(normalize_xy(np.array([2.0, 4.0, 6.0]), -1, 1), [-1.0, 0.0, 1.0])
