@@ -199,8 +199,64 @@ class DeviceRows:
         return out
 
 
+class _NoRows:
+    """A rank's block that holds no rows (a spread matrix with fewer blocks than ranks): every pass contributes nothing."""
+
+    def __init__(self, n_features):
+        self.n_rows, self.n_features = 0, int(n_features)
+
+    def colsum(self):
+        return np.zeros(self.n_features)
+
+    def center_at(self, mean):
+        return np.zeros(self.n_features), 0
+
+    def fetch(self, idx, centred=True):
+        return np.empty((0, self.n_features))
+
+    def seed_step(self, cand, cand_sq, use_closest):
+        return np.zeros(len(cand))
+
+    def seed_pick(self, which, vals=()):
+        return np.zeros(len(vals), dtype=np.int64)
+
+    def reset_labels(self):
+        pass
+
+    def lloyd(self, centers, update=True):
+        return np.zeros((len(centers), self.n_features)), np.zeros(len(centers)), 0
+
+    def own_distance(self, centers):
+        return np.empty(0)
+
+    def labels(self):
+        return np.empty(0, dtype=np.int32)
+
+    def estep(self, prec_chol, means, log_det, log_w, want_resp=True):
+        return 0.0
+
+    def resp_from_labels(self, k):
+        pass
+
+    def moments(self, component, shift):
+        return np.zeros((self.n_features + 1, self.n_features + 1))
+
+    gram = lambda self, shift: np.zeros((self.n_features + 1, self.n_features + 1))
+
+    def project(self, mean, components):
+        return np.empty((0, len(components)))
+
+    def close(self):
+        pass
+
+
 def _as_rows(X):
-    return (X, False) if isinstance(X, DeviceRows) else (DeviceRows(X), True)
+    if isinstance(X, (DeviceRows, _NoRows)):
+        return X, False
+    X = np.asarray(X)
+    if X.ndim == 2 and X.shape[0] == 0 and X.shape[1] > 0:
+        return _NoRows(X.shape[1]), True
+    return DeviceRows(X), True
 
 
 class _Shards:

@@ -70,8 +70,12 @@ def pca(X, n_components=2, reconstruct=False, comm=None):
     if isinstance(X, DeviceRows) or (hasattr(X, "gram") and hasattr(X, "project")):   # (tests plug a NumPy stand-in here)
         return _pca_resident(X, n_components, comm)
     if comm is not None and comm.world > 1:
-        with DeviceRows(X) as rows:
+        from ..clustering import _as_rows
+        rows, _ = _as_rows(X)
+        try:
             return _pca_resident(rows, n_components, comm)
+        finally:
+            rows.close()
     X = np.ascontiguousarray(X, dtype=np.float64)
     if X.ndim != 2:
         raise ValueError(f"Expected 2D array, got {X.ndim}D array instead")
