@@ -392,6 +392,9 @@ int zk_rows_gram(zk_rows* rows, const double* shift, double* gram_out);
  * ------------------------------------------------------------------------------------------------------ */
 int zk_rows_knn_correlation(zk_rows* rows, int n_neighbors, int local_connectivity, double perplexity, int64_t* ind_out,
                             double* dist_out, double* P_out);
+/* numpy.random.RandomState.choice(n, p = uniform) from its one uniform draw u (host arithmetic, no n-sized arrays): the first
+ * seed of scikit-learn's k-means++. */
+int zk_uniform_choice_index(int64_t n, double u, int64_t* index_out);
 int zk_force_layout_stage(double* xy, int64_t n_nodes, const int64_t* node1, const int64_t* node2, const double* weight,
                           int64_t n_pairs, const int64_t* nbrs_ind, int n_neighbors, int64_t num_iterations,
                           const double* force_params, int num_negative_samples, double learning_rate, int64_t* rng_state,

@@ -338,14 +338,22 @@ def _row_norms_sq(a):
     return np.einsum("ij,ij->i", a, a)                                       # sklearn.utils.extmath.row_norms(squared=True)
 
 
+def _uniform_choice(random_state, n):
+    """``random_state.choice(n, p=ones(n) / n)``: the same single draw from the generator and the same index (the cumulative
+    sums NumPy would build are replayed by ``zk_uniform_choice_index`` without the three n-sized arrays)."""
+    u = random_state.random_sample()
+    idx = c_int64()
+    _native.check(_native.load().zk_uniform_choice_index(int(n), float(u), byref(idx)), "zk_uniform_choice_index")
+    return int(idx.value)
+
+
 def _kmeans_plusplus(sh, n_clusters, random_state):
     """``_kmeans_plusplus`` (sklearn/cluster/_kmeans.py) on the centred matrix: same draws, distances on the device."""
     rows, n = sh.rows, sh.total
     n_local_trials = 2 + int(np.log(n_clusters))
     centers = np.empty((n_clusters, rows.n_features))
     indices = np.full(n_clusters, -1, dtype=int)
-    weight = np.ones(n)
-    center_id = random_state.choice(n, p=weight / weight.sum())
+    center_id = _uniform_choice(random_state, n)                             # random_state.choice(n, p=weight / weight.sum())
     centers[0] = sh.fetch([center_id])[0]
     indices[0] = center_id
     local_pots = rows.seed_step(centers[:1], _row_norms_sq(centers[:1]), use_closest=False)

@@ -55,3 +55,30 @@ def test_seg_lbs_segments_a_layout():
         assert (lbs[start:start + n] == want).mean() > 0.9
         start += n
     np.testing.assert_allclose(normalize_xy(np.array([2.0, 4.0, 6.0]), -1, 1), [-1.0, 0.0, 1.0])
+
+
+def test_uniform_choice_is_numpy_choice():
+    """The replay of ``RandomState.choice(n, p=uniform)``: same index, same generator state afterwards, for sizes around
+    powers of two, primes, and draws at the ends of the range."""
+    from mtflearn_amd.clustering import _uniform_choice
+    sizes = [1, 2, 3, 7, 10, 63, 64, 65, 1000, 4097, 65537, 100003, 1 << 20, 4068289]
+    for n in sizes:
+        w = np.ones(n)
+        for seed in range(12 if n < 10 ** 6 else 3):
+            a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+            assert _uniform_choice(a, n) == b.choice(n, p=w / w.sum())
+            assert a.random_sample() == b.random_sample()
+
+    class Fixed:                                           # extreme draws
+        def __init__(self, u):
+            self.u = u
+
+        def random_sample(self):
+            return self.u
+
+    for n in (5, 1000, 65537):
+        p = np.ones(n) / np.ones(n).sum()
+        cdf = p.cumsum()
+        cdf /= cdf[-1]
+        for u in (0.0, np.nextafter(1.0, 0.0), 0.5, 1.0 / n, np.nextafter(1.0 / n, 0), cdf[n // 3], np.nextafter(cdf[n // 3], 0)):
+            assert _uniform_choice(Fixed(u), n) == cdf.searchsorted(u, side="right"), (n, u)
