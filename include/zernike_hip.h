@@ -369,6 +369,9 @@ int zk_kmeans_seed_pick(zk_rows* rows, int which, const double* vals, int n_vals
 int zk_kmeans_step(zk_rows* rows, const double* centers, int k, int update, double* sums_out, double* counts_out,
                    int64_t* n_changed_out);
 int zk_kmeans_own_distance(zk_rows* rows, const double* centers, int k, double* dist_host);   /* |x - c[label]|^2, (N) */
+/* HIP-event time of the Lloyd kernel inside the zk_kmeans_step calls that follow (measurement aid of bench.py). */
+int zk_rows_profile(zk_rows* rows, int enable);
+double zk_rows_last_kernel_ms(const zk_rows* rows);
 /* Gaussian mixture (sklearn _estimate_log_gaussian_prob / _estimate_log_prob_resp / _estimate_gaussian_parameters):
  * E step with upper-triangular precision Cholesky factors (k, D, D), means (k, D), log-determinants and log weights (k):
  * responsibilities (k, N) and labels (first argmax) stay on the device, lse_sum_out = sum_r logsumexp_c; the M step's

@@ -49,6 +49,9 @@ struct zk_rows {
   size_t resp_bytes = 0;
   unsigned long long* d_count = nullptr;  // [4] integer counters
   std::vector<double> h_buf;
+  bool profile = false;          // HIP events around the main kernel of zk_kmeans_step / zk_gmm_estep / zk_gmm_moments
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  double last_kernel_ms = 0.0;
 };
 
 namespace {
@@ -678,6 +681,23 @@ int reduce_to_host(zk_rows* m, int n_blocks, int n, double* host_out) {
   return 0;
 }
 
+int prof_begin(zk_rows* m) {
+  if (m->profile) ZK_HIP(hipEventRecord(m->ev[0], m->stream));
+  return 0;
+}
+int prof_end(zk_rows* m) {
+  if (m->profile) ZK_HIP(hipEventRecord(m->ev[1], m->stream));
+  return 0;
+}
+int prof_read(zk_rows* m) {  // after the stream has been synchronised
+  if (m->profile) {
+    float ms = 0.f;
+    ZK_HIP(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
+    m->last_kernel_ms = ms;
+  }
+  return 0;
+}
+
 int check_lds(size_t bytes) {
   if (bytes > 160 * 1024) return zk_fail(ZK_E_BADARG, "too many features / clusters for one 160-KiB LDS tile");
   return 0;
@@ -712,6 +732,8 @@ extern "C" int zk_rows_destroy(zk_rows* m) {
   void* bufs[] = {m->d_mean, m->d_xsq, m->d_tab, m->d_part, m->d_red, m->d_seed[0], m->d_seed[1], m->d_labels, m->d_resp, m->d_count};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  for (hipEvent_t e : m->ev)
+    if (e) (void)hipEventDestroy(e);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return 0;
@@ -986,6 +1008,7 @@ extern "C" int zk_kmeans_step(zk_rows* m, const double* centers, int k, int upda
                        (const double*)m->d_mean, tab, tab + (size_t)m->D * KP, KP, k, m->d_labels, update, (double*)m->d_part,    \
                        m->d_count);                                                                                               \
   }
+  if ((rc = prof_begin(m))) return rc;
   switch (kmax) {
     case 4: ZK_LLOYD(4) break;
     case 8: ZK_LLOYD(8) break;
@@ -994,6 +1017,7 @@ extern "C" int zk_kmeans_step(zk_rows* m, const double* centers, int k, int upda
   }
 #undef ZK_LLOYD
   ZK_HIP(hipGetLastError());
+  if ((rc = prof_end(m))) return rc;
   unsigned long long chg = 0;
   if (update) {
     std::vector<double> red((size_t)k * D1);
@@ -1008,8 +1032,21 @@ extern "C" int zk_kmeans_step(zk_rows* m, const double* centers, int k, int upda
     ZK_HIP(hipStreamSynchronize(m->stream));
   }
   *n_changed_out = (int64_t)chg;
+  return prof_read(m);
+}
+
+// HIP-event timing of the main kernel of the next zk_kmeans_step calls (bench.py's roofline of the Lloyd pass)
+extern "C" int zk_rows_profile(zk_rows* m, int enable) {
+  if (!m) return zk_fail(ZK_E_BADARG, "null pointer");
+  ZK_ON_DEVICE(m->device);
+  if (enable && !m->ev[0]) {
+    ZK_HIP(hipEventCreate(&m->ev[0]));
+    ZK_HIP(hipEventCreate(&m->ev[1]));
+  }
+  m->profile = enable != 0;
   return 0;
 }
+extern "C" double zk_rows_last_kernel_ms(const zk_rows* m) { return m ? m->last_kernel_ms : 0.0; }
 
 // forget the labels (a new run starts from labels_old = -1)
 extern "C" int zk_rows_reset_labels(zk_rows* m) {

@@ -104,6 +104,8 @@ SYMBOLS = {
     "zk_kmeans_seed_step": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), c_int, c_int, POINTER(c_double)]),
     "zk_kmeans_seed_pick": (c_int, [c_void_p, c_int, POINTER(c_double), c_int, POINTER(c_int64)]),
     "zk_kmeans_step": (c_int, [c_void_p, POINTER(c_double), c_int, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "zk_rows_profile": (c_int, [c_void_p, c_int]),
+    "zk_rows_last_kernel_ms": (c_double, [c_void_p]),
     "zk_kmeans_own_distance": (c_int, [c_void_p, POINTER(c_double), c_int, POINTER(c_double)]),
     "zk_gmm_estep": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), c_int, c_int, POINTER(c_double)]),
     "zk_gmm_resp_from_labels": (c_int, [c_void_p, c_int]),

@@ -123,6 +123,12 @@ class DeviceRows:
                       "zk_kmeans_step")
         return sums, counts, int(changed.value)
 
+    def profile(self, enable=True):
+        _native.check(self._lib.zk_rows_profile(self._h, int(enable)), "zk_rows_profile")
+
+    def last_kernel_ms(self):
+        return float(self._lib.zk_rows_last_kernel_ms(self._h))
+
     def own_distance(self, centers):
         centers = np.ascontiguousarray(centers)
         out = np.empty(self.n_rows)
