@@ -158,3 +158,30 @@ def test_clustering_of_the_full_moment_matrix():
     np.testing.assert_allclose(centers, ref.cluster_centers_, rtol=0, atol=1e-9 * np.abs(ref.cluster_centers_).max())
     sizes = np.bincount(_relabel_by_size(labels))
     assert (np.diff(sizes) <= 0).all() and sizes.sum() == 4068289
+
+
+def test_symmetry_scores_of_the_full_moment_matrix():
+    """The rank-2 symmetry tail at BASELINE size: all 4 068 289 moment vectors of a 2048^2 frame through zk_moment_maps in
+    host chunks; 600 random rows against the oracle's rot_maps / to_complex / mirror_map, every row finite, and the key-point
+    route (zk_points_maps on the same frame) equal to it at the same positions."""
+    from oracle import zernike_oracle as zo
+    from mtflearn_amd.synthetic import honeycomb_frame
+    z = _zps(8, 32)
+    frame = honeycomb_frame(2048, seed=0)
+    zm = z.transform(frame)                                              # (45, 2048, 2048), dense
+    H = 2048 - 31
+    rows = np.ascontiguousarray(zm.data[:, 16:16 + H, 16:16 + H].reshape(45, -1).T)     # (4 068 289, 45): un-padded windows
+    assert rows.shape == (4068289, 45)
+    got = z.symmetry_of(rows)
+    assert got["rot_maps"].shape == (4068289, 4) and got["abs"].shape == (4068289, 25) and got["mirror_map"].shape == (4068289,)
+    assert np.isfinite(got["rot_maps"]).all() and np.isfinite(got["mirror_map"]).all()
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, len(rows), 600)
+    sub = rows[pick]
+    rel_close(got["rot_maps"][pick], zo.rot_maps(sub, z.n, z.m, [2, 3, 4, 6], p=2, m_unselect=(0, 1)), rtol=1e-9)
+    rel_close(got["abs"][pick], np.abs(zo.to_complex(sub, z.n, z.m)[0]), rtol=1e-12)
+    rel_close(got["mirror_map"][pick], zo.mirror_map(sub, z.n, z.m, theta=None, p=2, m_unselect=(0, 1)), rtol=1e-9)
+    ii, kk = np.divmod(pick, H)
+    at = z.symmetry_at(frame, np.column_stack([kk + 16, ii + 16]))       # (x, y) of the same windows
+    rel_close(at["rot_maps"], got["rot_maps"][pick], rtol=1e-6, atol_scale=1e-9)
+    rel_close(at["mirror_map"], got["mirror_map"][pick], rtol=1e-6, atol_scale=1e-9)
