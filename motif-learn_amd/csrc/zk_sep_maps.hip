@@ -340,7 +340,10 @@ __global__ __launch_bounds__(256) void zk_maps_planes_kernel(const double* __res
 
 // Rows form: the tail of a BATCH of moment vectors -- zmoments.to_complex / rot_maps / mirror_map on rank-2 data
 // (reference _zmoments.py:300-316, 420-493; e.g. the moments at key points), one lane per row of the (N, n_poly)
-// row-major matrix, outputs as rows of (N, n_folds), (N, N_c) and (N).
+// row-major matrix, outputs as rows of (N, n_folds), (N, N_c) and (N).  4 068 289 x 45: all outputs 1.87 ms, rot only 0.74 ms
+// (tools/time_rows_maps.py).  Tried: one wave per 64-row tile with both transpositions in LDS (coalesced copy in, |Z| / rot
+// assembled in LDS and stored as contiguous runs) -- 38 KiB of LDS per wave leaves four waves per CU and it ran SLOWER (2.12 /
+// 1.45 ms): the strided per-lane accesses here are served by the caches, and the tail's arithmetic wants the occupancy.
 template <int NMAX>
 __global__ __launch_bounds__(256) void zk_maps_rows_kernel(const double* __restrict__ mom, const double* __restrict__ trig,
                                                            double* __restrict__ rot_out, double* __restrict__ abs_out,
