@@ -375,11 +375,12 @@ double zk_rows_last_kernel_ms(const zk_rows* rows);
 /* Gaussian mixture (sklearn _estimate_log_gaussian_prob / _estimate_log_prob_resp / _estimate_gaussian_parameters):
  * E step with upper-triangular precision Cholesky factors (k, D, D), means (k, D), log-determinants and log weights (k):
  * responsibilities (k, N) and labels (first argmax) stay on the device, lse_sum_out = sum_r logsumexp_c; the M step's
- * sums of one component about `shift`: gram_out (D+1, D+1) = sum_r resp[c][r] [x_r - shift | 1]^T [x_r - shift | 1]. */
+ * sums of `count` (1 to 3) consecutive components about `shift` in one pass over the matrix: gram_out (count, D+1, D+1), each
+ * sum_r resp[c][r] [x_r - shift | 1]^T [x_r - shift | 1]. */
 int zk_gmm_estep(zk_rows* rows, const double* prec_chol, const double* means, const double* log_det, const double* log_w, int k,
                  int want_resp, double* lse_sum_out);
 int zk_gmm_resp_from_labels(zk_rows* rows, int k);               /* one-hot of the current labels */
-int zk_gmm_moments(zk_rows* rows, int component, const double* shift, double* gram_out);
+int zk_gmm_moments(zk_rows* rows, int component, int count, const double* shift, double* gram_out);  /* count 1..3 per pass */
 /* The same sums with unit weights (the Gram matrix about `shift` with the column sums and N: what a covariance needs). */
 int zk_rows_gram(zk_rows* rows, const double* shift, double* gram_out);
 

@@ -548,14 +548,17 @@ __global__ __launch_bounds__(256) void onehot_kernel(const int32_t* __restrict__
   for (int c = 0; c < k; ++c) resp[(long long)c * N + r] = l == c ? 1.0 : 0.0;
 }
 
-// part[block][group] = sum over the group's rows of w_r [x_r - shift | 1]^T [x_r - shift | 1]  (D+1 x D+1; upper triangle
-// written, mirrored), w = one plane of the responsibilities.  The (4T x 4T)-padded matrix is cut into 4 x 4 register
-// tiles; only the T (T + 1) / 2 tiles of the upper triangle are computed, one per thread, and the threads of a workgroup
-// form G groups of that many that share the LDS-staged 64-row tile and take every G-th row of it.
+// part[block][group][c] = sum over the group's rows of w_cr [x_r - shift | 1]^T [x_r - shift | 1]  (D+1 x D+1; upper triangle
+// written, mirrored) for C consecutive planes w_c of the responsibilities (unit weights when w is null).  The (4T x 4T)-padded
+// matrix is cut into 4 x 4 register tiles; only the T (T + 1) / 2 tiles of the upper triangle are computed, one per thread, and
+// the threads of a workgroup form G groups of that many that share the LDS-staged 64-row tile and take every G-th row of it.
+// C components per pass share the staging of the tile and the LDS reads of its rows (the kernel is bound by those, not by the
+// FMAs): one component per pass 0.59 ms each on 4 M x 45, three per pass: see profiles/r02_cluster_kernel_stats.csv.
+template <int C>
 __global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ X, long long N, int D, int T, int G,
                                                      const double* __restrict__ shift, const double* __restrict__ w,
                                                      double* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) double tile[];  // [64][4T] then [64] weights
+  extern __shared__ __attribute__((aligned(16))) double tile[];  // [64][4T] then [C][64] weights
   const int P = 4 * T, n_ut = T * (T + 1) / 2;
   double* wt = tile + 64 * P;
   const int tid = threadIdx.x, nthreads = blockDim.x;
@@ -564,11 +567,13 @@ __global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ 
   int ti = 0, rem = u;
   while (rem >= T - ti) rem -= T - ti, ++ti;
   const int tj = ti + rem;
-  double acc[4][4];
+  double acc[C][4][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[c][a][b] = 0.0;
   // columns D .. P-1 never change: the constant 1, then zero padding
   for (int e = tid; e < 64 * (P - D); e += nthreads) {
     const int r = e / (P - D), c = D + e - r * (P - D);
@@ -596,36 +601,47 @@ __global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ 
         }
       }
     }
-    for (int r = tid; r < 64; r += nthreads) wt[r] = r0 + r < N ? (w ? w[r0 + r] : 1.0) : 0.0;
+    for (int e = tid; e < 64 * C; e += nthreads) {
+      const int c = e >> 6, r = e & 63;
+      wt[e] = r0 + r < N ? (w ? w[(long long)c * N + r0 + r] : 1.0) : 0.0;
+    }
     __syncthreads();
     if (worker) {
 #pragma unroll 2
       for (int r = g; r < 64; r += G) {
         const double* row = tile + r * P;
-        const double wr = wt[r];
         double xi[4], xj[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) xi[a] = row[4 * ti + a] * wr, xj[a] = row[4 * tj + a];
+        for (int a = 0; a < 4; ++a) xi[a] = row[4 * ti + a], xj[a] = row[4 * tj + a];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < C; ++c) {
+          const double wr = wt[c * 64 + r];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(xi[a], xj[b], acc[a][b]);
+          for (int a = 0; a < 4; ++a) {
+            const double xw = xi[a] * wr;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[c][a][b] = __builtin_fma(xw, xj[b], acc[c][a][b]);
+          }
+        }
       }
     }
   }
   if (worker) {
     const int D1 = D + 1;
-    double* out = part + ((long long)blockIdx.x * G + g) * D1 * D1;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int c = 0; c < C; ++c) {
+      double* out = part + (((long long)blockIdx.x * G + g) * C + c) * D1 * D1;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int i = 4 * ti + a, j = 4 * tj + b;
-        if (i < D1 && j < D1 && i <= j) {
-          out[i * D1 + j] = acc[a][b];
-          if (i != j) out[j * D1 + i] = acc[a][b];
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int i = 4 * ti + a, j = 4 * tj + b;
+          if (i < D1 && j < D1 && i <= j) {
+            out[i * D1 + j] = acc[c][a][b];
+            if (i != j) out[j * D1 + i] = acc[c][a][b];
+          }
         }
-      }
+    }
   }
 }
 
@@ -1170,8 +1186,9 @@ extern "C" int zk_gmm_resp_from_labels(zk_rows* m, int k) {
   return 0;
 }
 
-// sum_r w_r [x_r - shift | 1]^T [x_r - shift | 1] with w = one plane of the responsibilities, or 1 (w_dev null)
-static int rows_gram(zk_rows* m, const double* w_dev, const double* shift, double* gram_out) {
+// sum_r w_cr [x_r - shift | 1]^T [x_r - shift | 1] for `count` (1 to 3) consecutive planes of the responsibilities starting at
+// w_dev, or with unit weights (w_dev null, count 1); gram_out (count, D+1, D+1)
+static int rows_gram(zk_rows* m, const double* w_dev, int count, const double* shift, double* gram_out) {
   const int D = m->D, D1 = D + 1, T = (D1 + 3) / 4, n_ut = T * (T + 1) / 2;
   m->h_buf.assign(shift, shift + D);
   int rc = upload_tab(m, m->h_buf);
@@ -1179,30 +1196,44 @@ static int rows_gram(zk_rows* m, const double* w_dev, const double* shift, doubl
   if (rc) return rc;
   const int threads = std::max(256, (n_ut + 63) & ~63);
   const int G = std::min(threads / n_ut, 16);
-  const size_t lds = ((size_t)64 * 4 * T + 64) * sizeof(double);
+  const size_t lds = ((size_t)64 * 4 * T + 64 * count) * sizeof(double);
   int per_cu = (int)std::min<size_t>((160 * 1024) / (lds + 512), (size_t)(2048 / threads));
-  per_cu = std::max(1, std::min(per_cu, 6));
+  per_cu = std::max(1, std::min(per_cu, count > 1 ? 4 : 6));
   long long blocks = std::min<long long>((m->N + 63) / 64, (long long)per_cu * m->n_cu);
-  if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)blocks * G * D1 * D1 * sizeof(double)))) return rc;
-  if ((rc = allow_lds(wgram_kernel, lds))) return rc;
-  hipLaunchKernelGGL(wgram_kernel, dim3((unsigned)blocks), dim3(threads), lds, m->stream, m->X, (long long)m->N, D, T, G,
-                     (const double*)m->d_tab, w_dev, (double*)m->d_part);
+  if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)blocks * G * count * D1 * D1 * sizeof(double)))) return rc;
+  if ((rc = prof_begin(m))) return rc;
+#define ZK_WGRAM(CC)                                                                                                        \
+  {                                                                                                                         \
+    if ((rc = allow_lds(wgram_kernel<CC>, lds))) return rc;                                                                 \
+    hipLaunchKernelGGL(wgram_kernel<CC>, dim3((unsigned)blocks), dim3(threads), lds, m->stream, m->X, (long long)m->N, D, T, \
+                       G, (const double*)m->d_tab, w_dev, (double*)m->d_part);                                              \
+  }
+  switch (count) {
+    case 1: ZK_WGRAM(1) break;
+    case 2: ZK_WGRAM(2) break;
+    default: ZK_WGRAM(3) break;
+  }
+#undef ZK_WGRAM
   ZK_HIP(hipGetLastError());
-  return reduce_to_host(m, (int)(blocks * G), D1 * D1, gram_out);
+  if ((rc = prof_end(m))) return rc;
+  if ((rc = reduce_to_host(m, (int)(blocks * G), count * D1 * D1, gram_out))) return rc;
+  return prof_read(m);
 }
 
-// M-step sums of component c about `shift` (D): gram_out (D+1, D+1) = sum_r resp[c][r] [x_r - shift | 1]^T [x_r - shift | 1]
-// -- second moments, first moments in the last row / column, the component's weight in the corner.
-extern "C" int zk_gmm_moments(zk_rows* m, int c, const double* shift, double* gram_out) {
+// M-step sums about `shift` (D) of `count` (1 to 3) consecutive components starting at c: gram_out (count, D+1, D+1), each
+// sum_r resp[c][r] [x_r - shift | 1]^T [x_r - shift | 1] -- second moments, first moments in the last row / column, the
+// component's weight in the corner.
+extern "C" int zk_gmm_moments(zk_rows* m, int c, int count, const double* shift, double* gram_out) {
   if (!m || !shift || !gram_out) return zk_fail(ZK_E_BADARG, "null pointer");
-  if (!m->d_resp || c < 0 || (size_t)(c + 1) * m->N * sizeof(double) > m->resp_bytes) return zk_fail(ZK_E_BADARG, "no such component");
+  if (count < 1 || count > 3) return zk_fail(ZK_E_BADARG, "1 to 3 components per pass");
+  if (!m->d_resp || c < 0 || (size_t)(c + count) * m->N * sizeof(double) > m->resp_bytes) return zk_fail(ZK_E_BADARG, "no such component");
   ZK_ON_DEVICE(m->device);
-  return rows_gram(m, (const double*)m->d_resp + (size_t)c * m->N, shift, gram_out);
+  return rows_gram(m, (const double*)m->d_resp + (size_t)c * m->N, count, shift, gram_out);
 }
 
 // The same sums with unit weights: everything a covariance needs (pca), in a fixed summation order.
 extern "C" int zk_rows_gram(zk_rows* m, const double* shift, double* gram_out) {
   if (!m || !shift || !gram_out) return zk_fail(ZK_E_BADARG, "null pointer");
   ZK_ON_DEVICE(m->device);
-  return rows_gram(m, nullptr, shift, gram_out);
+  return rows_gram(m, nullptr, 1, shift, gram_out);
 }

@@ -109,7 +109,7 @@ SYMBOLS = {
     "zk_kmeans_own_distance": (c_int, [c_void_p, POINTER(c_double), c_int, POINTER(c_double)]),
     "zk_gmm_estep": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), c_int, c_int, POINTER(c_double)]),
     "zk_gmm_resp_from_labels": (c_int, [c_void_p, c_int]),
-    "zk_gmm_moments": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_double)]),
+    "zk_gmm_moments": (c_int, [c_void_p, c_int, c_int, POINTER(c_double), POINTER(c_double)]),
     "zk_rows_gram": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "zk_rows_knn_correlation": (c_int, [c_void_p, c_int, c_int, c_double, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     "zk_uniform_choice_index": (c_int, [c_int64, c_double, POINTER(c_int64)]),

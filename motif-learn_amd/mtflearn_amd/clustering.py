@@ -151,12 +151,17 @@ class DeviceRows:
     def resp_from_labels(self, k):
         _native.check(self._lib.zk_gmm_resp_from_labels(self._h, int(k)), "zk_gmm_resp_from_labels")
 
-    def moments(self, component, shift):
+    def moments(self, component, shift, count=None):
+        """Weighted moment matrix of one component, or (``count`` given) of ``count`` consecutive ones -> (count, D+1, D+1);
+        up to three components share one pass over the matrix."""
         shift = np.ascontiguousarray(shift)
         d1 = self.n_features + 1
-        out = np.empty((d1, d1))
-        _native.check(self._lib.zk_gmm_moments(self._h, int(component), _p(shift), _p(out)), "zk_gmm_moments")
-        return out
+        n = 1 if count is None else int(count)
+        out = np.empty((n, d1, d1))
+        for c0 in range(0, n, 3):
+            cc = min(3, n - c0)
+            _native.check(self._lib.zk_gmm_moments(self._h, int(component) + c0, cc, _p(shift), _p(out[c0:c0 + cc])), "zk_gmm_moments")
+        return out[0] if count is None else out
 
 
     def gram(self, shift):
@@ -244,8 +249,9 @@ class _NoRows:
     def resp_from_labels(self, k):
         pass
 
-    def moments(self, component, shift):
-        return np.zeros((self.n_features + 1, self.n_features + 1))
+    def moments(self, component, shift, count=None):
+        d1 = self.n_features + 1
+        return np.zeros((d1, d1) if count is None else (int(count), d1, d1))
 
     gram = lambda self, shift: np.zeros((self.n_features + 1, self.n_features + 1))
 
@@ -552,8 +558,9 @@ def _gaussian_parameters(sh, k, shift, reg_covar, covariance_type):
     eps10 = 10 * np.finfo(np.float64).eps
     nk, means = np.empty(k), np.empty((k, d))
     scatter = np.empty((k, d, d))                                             # sum_r w (x - mean)(x - mean)^T
+    grams = sh.sum(rows.moments(0, shift, count=k))                          # three components per pass over the matrix
     for c in range(k):
-        g = sh.sum(rows.moments(c, shift))
+        g = grams[c]
         a, b, n0 = g[:d, :d], g[d, :d], g[d, d]
         nk[c] = n0 + eps10
         mt = b / nk[c]

@@ -97,9 +97,10 @@ class HostRows:
     def project(self, mean, components):
         return (self.X - mean) @ np.asarray(components).T
 
-    def moments(self, component, shift):
+    def moments(self, component, shift, count=None):
         z = np.concatenate([self.X - shift, np.ones((self.n_rows, 1))], axis=1)
-        return (z * self.resp[:, component][:, None]).T @ z
+        one = lambda c: (z * self.resp[:, c][:, None]).T @ z
+        return one(component) if count is None else np.stack([one(component + c) for c in range(count)])
 
     def close(self):
         pass
