@@ -301,7 +301,8 @@ def worker(args):
     elapsed, launches, kernel_ms = (el_gather, l_gather, ms_gather) if in_step else (el_kernel, l_kernel, ms_kernel)
     side = {}
     if not args.only_timed_loop and not args.no_clustering:
-        side["clustering"] = clustering_section(comm, world, dev, mine, n_local, n_poly)
+        side["clustering"] = clustering_section(comm, world, dev, mine, n_local, n_poly,
+                                                cpu_sample=0 if (args.no_cpu_baseline or world > 1) else 500000)
     if world > 1 and not args.only_timed_loop:
         side.update(multi_rank_sections(args, comm, rank, world, dev, plan, z))
 
@@ -359,7 +360,7 @@ def worker(args):
 # downstream consumer on the moment matrix where the timed kernel left it (every rank takes part; rank 0 reports):
 # k-means of ALL ranks' moments without gathering them -- the ranks exchange k x D sums, then 4 bytes of label per row
 # ---------------------------------------------------------------------------------------------------------
-def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4):
+def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4, cpu_sample=0):
     import numpy as np
     import torch
     from mtflearn_amd.clustering import DeviceRows, kmeans_fit, gather_labels
@@ -390,7 +391,17 @@ def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4):
     if comm is not None:
         agree = all(b == sizes.tobytes() for b in comm.allgather_host(sizes.tobytes()))
     n_total = world * n_local
-    return {"workload": f"kmeans_lbs flow (scikit-learn KMeans(n_clusters={k}, random_state=0): k-means++ seeding, Lloyd) on the "
+    cpu = None
+    if cpu_sample:                                                   # what the reference's kmeans_lbs runs: scikit-learn on the host
+        from sklearn.cluster import KMeans
+        sample = mine[:cpu_sample].cpu().numpy()
+        t0 = time.perf_counter()
+        model = KMeans(n_clusters=k, random_state=0).fit(sample)
+        s_cpu = time.perf_counter() - t0
+        cpu = {"value": len(sample) * model.n_iter_ / s_cpu, "unit": "rows x Lloyd iterations / s", "cores": os.cpu_count(),
+               "kind": "dependency (scikit-learn: the call inside the reference wrapper)", "sample": f"sklearn.cluster.KMeans(n_clusters={k}, random_state=0).fit on the first {len(sample)} "
+               f"moment vectors ({model.n_iter_} iterations, {s_cpu:.2f} s) -- the call inside the reference's kmeans_lbs"}
+    out = {"workload": f"kmeans_lbs flow (scikit-learn KMeans(n_clusters={k}, random_state=0): k-means++ seeding, Lloyd) on the "
                         f"({n_total}, {n_poly}) float64 moment matrix of the timed step, resident in HBM, "
                         + (f"one block per rank: the ranks exchange {k} x {n_poly + 1} sums per pass and gather 4-byte labels, "
                            "never the moments" if world > 1 else "adopted where the batch kernel wrote it"),
@@ -401,6 +412,11 @@ def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4):
                                         "frac": (8 * n_poly + 4) * n_local / (kernel_ms * 1e-3) / 1e9 / 8000.0}},
             "rows_per_s_end_to_end": n_total / (s_fit + s_gather), "cluster_sizes": sizes.tolist(), "ranks_agree": bool(agree),
             "label_bytes_gathered": 4 * n_total, "moment_bytes_not_gathered": 8 * n_poly * n_total}
+    out["rows_x_iterations_per_s"] = n_total * n_iter / s_fit
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+        out["gpu_over_cpu"] = out["rows_x_iterations_per_s"] / cpu["value"]
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------
