@@ -233,3 +233,33 @@ def test_row_passes_on_edge_shapes():
             np.testing.assert_allclose(dev.gram(mean), g_h, rtol=1e-11, atol=1e-11 * np.abs(g_h).max())
             comp = rng.standard_normal((min(d, 20), d))
             np.testing.assert_allclose(dev.project(mean, comp), host.project(mean, comp), rtol=1e-11, atol=1e-11)
+
+
+def test_sharded_control_flow_on_the_device_passes():
+    """The sharded code path (``comm=``) driving real device passes: a two-rank communicator whose other rank holds no rows and
+    contributes zeros to every sum -- labels, centres, mixture labels and PCA scores must equal the single-block run."""
+    from mtflearn_amd.clustering import DeviceRows, kmeans_fit, gmm_fit_predict, kmeans_lbs, _relabel_by_size
+    from mtflearn_amd.features import pca
+
+    class OtherRankEmpty:
+        rank, world = 0, 2
+
+        def allgather_host(self, payload):
+            return [payload, bytes(len(payload))]
+
+    X = _moment_matrix(step=3)
+    comm = OtherRankEmpty()
+    with DeviceRows(X) as rows:
+        one = kmeans_fit(rows, 5, random_state=2)
+        two = kmeans_fit(rows, 5, random_state=2, comm=comm)
+        np.testing.assert_array_equal(one[0], two[0])
+        np.testing.assert_array_equal(one[1], two[1])
+        assert one[2] == two[2]
+        np.testing.assert_array_equal(kmeans_lbs(rows, 5, random_state=2, comm=comm), _relabel_by_size(one[0]))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            g1 = gmm_fit_predict(rows, 3, covariance_type="full", random_state=1)
+            g2 = gmm_fit_predict(rows, 3, covariance_type="full", random_state=1, comm=comm)
+        np.testing.assert_array_equal(g1[0], g2[0])
+        assert g1[1:] == g2[1:]
+        np.testing.assert_array_equal(pca(rows, 4), pca(rows, 4, comm=comm))

@@ -150,6 +150,9 @@ def test_rccl_communicator_world_one(tmp_path, rendezvous):
     try:
         assert (comm.rank, comm.world) == (0, 1)
         assert comm.allgather_host(b"abcd") == [b"abcd"]
+        big = np.random.default_rng(0).integers(0, 255, 3_000_001, dtype=np.uint8).tobytes()     # grows the staging buffer
+        assert comm.allgather_host(big) == [big]
+        assert comm.allgather_host(b"xy") == [b"xy"] and comm.allgather_host(big[:70000]) == [big[:70000]]
         assert comm.max_over_ranks(2.5) == 2.5
         comm.barrier()
         z = _zps(8, 32)
