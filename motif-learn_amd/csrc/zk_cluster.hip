@@ -294,6 +294,9 @@ __device__ __forceinline__ double masked_column_sum(const double* __restrict__ t
 // KMAX > 0: k <= KMAX, the per-cluster column sums live in registers (lane = column; the rows of cluster c are the set bits
 // of ballot(label == c), walked by a scalar loop); KMAX = 0: any k, LDS floating-point adds into a wave-private table
 // (an LDS f64 atomic costs ~280 cycles per wave: 2.4x the whole pass at k = 6, so only where the registers do not reach).
+// Tried: two waves per tile, both computing the labels (no exchange) and splitting the clusters of the column sums by
+// parity, one tile buffer per pair (twelve waves per CU): 0.48 vs 0.47 ms per call at (4 M x 45, k = 6), 0.75 vs 0.83 at
+// (2 M x 91, k = 12) -- the redundant distance pass and the two barriers per tile eat what the occupancy gives.  Not kept.
 template <int KMAX>
 __global__ __launch_bounds__(64) void lloyd_kernel(const double* __restrict__ X, long long N, int D, int nbuf,
                                                    const double* __restrict__ mean, const double* __restrict__ Ct,
