@@ -301,8 +301,11 @@ def worker(args):
     elapsed, launches, kernel_ms = (el_gather, l_gather, ms_gather) if in_step else (el_kernel, l_kernel, ms_kernel)
     side = {}
     if not args.only_timed_loop and not args.no_clustering:
-        side["clustering"] = clustering_section(comm, world, dev, mine, n_local, n_poly,
-                                                cpu_sample=0 if (args.no_cpu_baseline or world > 1) else 500000)
+        try:
+            side["clustering"] = clustering_section(comm, world, dev, mine, n_local, n_poly,
+                                                    cpu_sample=0 if (args.no_cpu_baseline or world > 1) else 500000)
+        except Exception as exc:                                     # a side section must not cost the line
+            side["clustering"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world > 1 and not args.only_timed_loop:
         side.update(multi_rank_sections(args, comm, rank, world, dev, plan, z))
 
