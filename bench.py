@@ -77,19 +77,22 @@ def launch(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
-    code = 0
+    code, first = 0, procs[0]
+    rank0_code = None
     while procs:
         for p in list(procs):
             rc = p.poll()
             if rc is None:
                 continue
             procs.remove(p)
+            if p is first:
+                rank0_code = rc
             if rc != 0 and code == 0:
                 code = rc
                 for q in procs:                                           # one rank failed: stop the others
                     q.terminate()
         time.sleep(0.05)
-    return code
+    return 0 if rank0_code == 0 else code                                  # rank 0 delivered the line: that is the job
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -299,22 +302,8 @@ def worker(args):
 
     in_step = world > 1 and not args.kernel_only_value
     elapsed, launches, kernel_ms = (el_gather, l_gather, ms_gather) if in_step else (el_kernel, l_kernel, ms_kernel)
-    side = {}
-    if not args.only_timed_loop and not args.no_clustering:
-        try:
-            side["clustering"] = clustering_section(comm, world, dev, mine, n_local, n_poly,
-                                                    cpu_sample=0 if (args.no_cpu_baseline or world > 1) else 500000)
-        except Exception as exc:                                     # a side section must not cost the line
-            side["clustering"] = {"error": f"{type(exc).__name__}: {exc}"}
-    if world > 1 and not args.only_timed_loop:
-        side.update(multi_rank_sections(args, comm, rank, world, dev, plan, z))
 
-    if rank != 0:
-        if comm is not None:
-            comm.barrier()
-            comm.close()
-        return
-
+    # ---- the line's contract keys are complete here; the side sections below only add to it -----------------------------
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total / (elapsed / args.steps)
     per_patch = rl.batch_bytes_per_patch(K, args.n_max, 4)
@@ -342,6 +331,41 @@ def worker(args):
     }
     if gather is not None:
         result["allgather"] = gather
+
+    # N > 1: the side sections run collectives nobody here could rehearse on real links.  If one of them stalls, rank 0 still
+    # delivers the line it already has (and says so), and every rank leaves.
+    watchdog = None
+    if world > 1 and not args.only_timed_loop:
+        import threading
+        limit = float(os.environ.get("ZK_BENCH_SIDE_TIMEOUT", "420"))
+
+        def give_up():
+            if rank == 0:
+                result["side_sections"] = f"not finished within {limit:.0f} s; omitted"
+                os.write(json_fd, (json.dumps(result) + "\n").encode())
+            os._exit(0)
+
+        watchdog = threading.Timer(limit, give_up)                      # the ranks left the same barrier a moment ago: same deadline
+        watchdog.daemon = True
+        watchdog.start()
+
+    side = {}
+    if not args.only_timed_loop and not args.no_clustering:
+        try:
+            side["clustering"] = clustering_section(comm, world, dev, mine, n_local, n_poly,
+                                                    cpu_sample=0 if (args.no_cpu_baseline or world > 1) else 500000)
+        except Exception as exc:                                     # a side section must not cost the line
+            side["clustering"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if world > 1 and not args.only_timed_loop:
+        side.update(multi_rank_sections(args, comm, rank, world, dev, plan, z))
+    if watchdog is not None:
+        watchdog.cancel()
+
+    if rank != 0:
+        if comm is not None:
+            comm.barrier()
+            comm.close()
+        return
     result.update(side)
 
     if world == 1 and not args.only_timed_loop:
