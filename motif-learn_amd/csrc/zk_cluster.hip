@@ -566,8 +566,8 @@ template <int C>
 __global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ X, long long N, int D, int T, int G,
                                                      const double* __restrict__ shift, const double* __restrict__ w,
                                                      double* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) double tile[];  // [64][4T] then [C][64] weights
-  const int P = 4 * T, n_ut = T * (T + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) double tile[];  // [64][4T + 4] then [C][64] weights
+  const int P = 4 * T + 4, n_ut = T * (T + 1) / 2;  // + 4: a pitch of 4T doubles puts every other row on the same LDS banks
   double* wt = tile + 64 * P;
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int g = tid / n_ut, u = tid - g * n_ut;
@@ -1213,7 +1213,7 @@ static int rows_gram(zk_rows* m, const double* w_dev, int count, const double* s
   if (rc) return rc;
   const int threads = std::max(256, (n_ut + 63) & ~63);
   const int G = std::min(threads / n_ut, 16);
-  const size_t lds = ((size_t)64 * 4 * T + 64 * count) * sizeof(double);
+  const size_t lds = ((size_t)64 * (4 * T + 4) + 64 * count) * sizeof(double);
   int per_cu = (int)std::min<size_t>((160 * 1024) / (lds + 512), (size_t)(2048 / threads));
   per_cu = std::max(1, std::min(per_cu, count > 1 ? 4 : 6));
   long long blocks = std::min<long long>((m->N + 63) / 64, (long long)per_cu * m->n_cu);
