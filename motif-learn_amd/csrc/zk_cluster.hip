@@ -419,7 +419,9 @@ __global__ __launch_bounds__(64) void owndist_kernel(const double* __restrict__ 
 //  tools/micro_mfma64.hip, against the 28-48 of SGPR-fed v_fma_f64 -- with wave = 16-row block, A from the LDS tile, B = the
 //  factor from memory: correct on every test, but 3.4 ms against 2.1: every lane fetches its own element of the factor, 512 B
 //  per MFMA, 19 TB through L1 / L2 per pass over 4 M rows, where a scalar operand is fetched once per wave and used by 64 lanes x
-//  16 FMAs.  Reusing B across row blocks needs a different split of the work; not pursued.)
+//  16 FMAs.  Reusing B across row blocks needs a different split of the work; not pursued.
+//  Also tried: two rows per lane (128-row tiles) so that every scalar operand feeds two FMAs: 2.03 against 2.08 ms -- the
+//  halved occupancy takes back what the halved scalar traffic gives.)
 // ZK_EWAVES waves share a tile (every wave holds the same 64 rows, lane = row): the (component, column block) pairs are dealt
 // to the waves by cost on the host (`plan`: per wave a count and its (c, j0) pairs), each wave adds the squared norms of its
 // blocks into its own [k][64] LDS table, and after a barrier every wave combines the tables in wave order -- redundant but
