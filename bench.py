@@ -70,29 +70,150 @@ def launch(args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    one_device = bool(os.environ.get("ZK_BENCH_ONE_DEVICE"))
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if one_device and os.environ.get("ZK_BENCH_BACKEND", "rccl") == "rccl" and not os.environ.get("ZK_BENCH_SAME_HOSTID"):
+            # rehearsal of N RCCL ranks on ONE GPU: a host id per rank (mtflearn_amd.distributed.one_gpu_rank_env)
+            from mtflearn_amd.distributed import one_gpu_rank_env
+            env = one_gpu_rank_env(r, env)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
-    code, first = 0, procs[0]
-    rank0_code = None
+    code, kill_at = 0, None
     while procs:
         for p in list(procs):
             rc = p.poll()
             if rc is None:
                 continue
             procs.remove(p)
-            if p is first:
-                rank0_code = rc
             if rc != 0 and code == 0:
-                code = rc
-                for q in procs:                                           # one rank failed: stop the others
-                    q.terminate()
+                code = rc if rc > 0 else 128 - rc                          # a signal's number, shell style
+                print(f"[bench] a rank exited with {rc}: stopping the others", file=sys.stderr)
+                for q in procs:                                           # one rank failed: stop the others (rank 0 still
+                    q.terminate()                                         # delivers what it has, see Deadman)
+                kill_at = time.time() + 20.0
+        if kill_at is not None and time.time() > kill_at:
+            for q in procs:                                               # exactly the children started above
+                q.kill()
+            kill_at = None
         time.sleep(0.05)
-    return 0 if rank0_code == 0 else code                                  # rank 0 delivered the line: that is the job
+    return code                                                           # any rank failed or timed out -> non-zero
+
+
+# ---------------------------------------------------------------------------------------------------------
+# failure handling at N > 1: nothing may end as "exit 0 with a plausible line"
+# ---------------------------------------------------------------------------------------------------------
+class TracedComm:
+    """Delegates to a communicator and remembers the call in flight, for the report of a stalled run."""
+
+    def __init__(self, comm):
+        self._c = comm
+        self.in_flight = None
+        self.n_calls = 0
+
+    def __getattr__(self, name):
+        attr = getattr(self._c, name)
+        if not callable(attr):
+            return attr
+
+        def call(*a, **k):
+            self.n_calls += 1
+            self.in_flight = f"{name}({', '.join(_brief(x) for x in a)}) [call #{self.n_calls}]"
+            out = attr(*a, **k)
+            self.in_flight = None
+            return out
+        return call
+
+
+def _brief(x):
+    if hasattr(x, "shape") and hasattr(x, "dtype"):
+        return f"<{tuple(x.shape)} {str(x.dtype).replace('torch.', '')}>"
+    if isinstance(x, (bytes, bytearray)):
+        return f"<{len(x)} bytes>"
+    return repr(x)
+
+
+class Deadman:
+    """One per rank.  Knows the phase the rank is in, the line rank 0 could deliver so far, and ends the process
+    NON-ZERO -- after saying on stderr where it was (phase, collective in flight, the stacks of every thread) -- when
+    a phase overruns its limit, when SIGTERM arrives (the launcher stopping the survivors of a failed rank) or when the
+    caller asks (verification failure, communicator unavailable).  Rank 0 first writes the line it has: with `value`
+    null and an "unmeasured" reason if the timed region was not completed and verified, else the complete contract
+    keys with "side_sections" naming what is missing."""
+
+    def __init__(self, rank, world, json_fd, args):
+        import threading
+        self.rank, self.world, self.json_fd, self.args = rank, world, json_fd, args
+        self.phase, self.result, self.comm = "start-up", None, None
+        self._timer, self._lock, self._done = None, threading.Lock(), False
+        if world > 1:
+            # SIGTERM must be seen even while the main thread sits in a C call (a stalled collective): the C-level
+            # handler writes the signal number to a pipe, a helper thread reads it
+            import signal
+            r, w = os.pipe()
+            os.set_blocking(w, False)
+            signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+            signal.signal(signal.SIGTERM, lambda *_: None)
+            t = threading.Thread(target=self._on_signal, args=(r,), daemon=True)
+            t.start()
+
+    def _on_signal(self, fd):
+        import signal
+        while True:
+            data = os.read(fd, 16)
+            if not data:
+                return
+            if signal.SIGTERM in data:
+                self.fire("stopped by SIGTERM (another rank failed or the launcher gave up)", 143)
+
+    def enter(self, phase, limit_s=None):
+        """Start a phase; with a limit, overrunning it ends the run."""
+        import threading
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+        self.phase = phase
+        if limit_s and self.world > 1:
+            self._timer = threading.Timer(limit_s, self.fire, args=(f"no progress for {limit_s:.0f} s", 124))
+            self._timer.daemon = True
+            self._timer.start()
+
+    def null_line(self, reason):
+        a = self.args
+        return {"metric": "patches/s (32x32, n_max=8) + achieved HBM GB/s vs roofline", "value": None, "unit": "patches/s",
+                "n_gpus": self.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"configs[1]: synthetic {a.frame}x{a.frame} frame per GPU, dense {a.size}-px windows, "
+                                       f"n_max={a.n_max}"},
+                "unmeasured": reason}
+
+    def fire(self, reason, code):
+        import faulthandler
+        with self._lock:
+            if self._done:
+                return
+            self._done = True
+        where = f"phase '{self.phase}'"
+        if self.comm is not None and getattr(self.comm, "in_flight", None):
+            where += f", collective in flight: {self.comm.in_flight}"
+        msg = f"{reason} in {where}"
+        try:
+            sys.stderr.write(f"[bench] rank {self.rank}/{self.world}: {msg}; stacks of every thread follow\n")
+            sys.stderr.flush()
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            sys.stderr.flush()
+        finally:
+            if self.rank == 0:
+                line = self.result
+                if line is None:
+                    line = self.null_line(msg)
+                else:
+                    line = dict(line, side_sections=f"incomplete: {msg}")
+                os.write(self.json_fd, (json.dumps(line) + "\n").encode())
+            os._exit(code)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -196,9 +317,12 @@ def worker(args):
     from mtflearn_amd import distributed as D
     from mtflearn_amd.synthetic import honeycomb_frame
 
+    dead = Deadman(rank, world, json_fd, args)
+    limit = float(os.environ.get("ZK_BENCH_PHASE_TIMEOUT", os.environ.get("ZK_BENCH_SIDE_TIMEOUT", "420")))
     comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dead.enter("communicator start-up", limit)
         if backend == "gloo":
             import torch.distributed as dist
             dist.init_process_group("gloo")
@@ -209,14 +333,11 @@ def worker(args):
             try:
                 comm = D.RcclComm(local_rank, rank, world, path=path)
             except RuntimeError as exc:
-                # the library's own RCCL endpoint could not be brought up (no librccl to dlopen, rendezvous failure):
-                # fall back to the test-aid communicator on torch.distributed's RCCL backend rather than produce no
-                # line at all, and say so in the JSON
-                import torch.distributed as dist
-                print(f"[bench] rank {rank}: zk_comm unavailable ({exc}); falling back to torch.distributed nccl", file=sys.stderr)
-                dist.init_process_group("nccl", device_id=dev)
-                comm = D.TorchComm()
-                backend = f"torch.distributed nccl (fallback: {exc})"
+                # the product's collective is what this line measures: without it there is no `value`, and no stand-in
+                # communicator is substituted
+                dead.fire(f"product collective unavailable: {exc}", 3)
+        comm = TracedComm(comm)
+        dead.comm = comm
 
     K, H = args.size, args.frame
     z = ZPs(n_max=args.n_max, size=K)
@@ -255,20 +376,33 @@ def worker(args):
             step()
         fence()
         dt = time.perf_counter() - t0
-        launches, kernel_ms = plan.profile_read()
+        per_launch = plan.profile_read_launches()
         plan.profile(False)
+        launches, kernel_ms = len(per_launch), float(sum(per_launch))
         if comm is not None:
             dt = comm.max_over_ranks(dt)
             kernel_ms = comm.max_over_ranks(kernel_ms)
-        return dt, launches, kernel_ms
+        # kernel time of every timed step (a step = launches / steps consecutive launches), this rank
+        per = launches // args.steps if launches >= args.steps else 1
+        step_ms = sorted(sum(per_launch[i * per:(i + 1) * per]) for i in range(len(per_launch) // per))
+        spread = {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1]} if step_ms else None
+        return dt, launches, kernel_ms, spread
 
-    el_kernel, l_kernel, ms_kernel = timed_loop(step_kernel)
+    dead.enter("timed loop (kernels only)", limit)
+    el_kernel, l_kernel, ms_kernel, spread_kernel = timed_loop(step_kernel)
     gather = None
+    verified = True
     if world > 1:
-        el_gather, l_gather, ms_gather = timed_loop(step_gather)
+        dead.enter("timed loop (kernel + all-gather per step)", limit)
+        el_gather, l_gather, ms_gather, spread_gather = timed_loop(step_gather)
+        dead.enter("all-gather verification", limit)
         # verification: my block is what my kernel wrote; every other block carries its owner's checksum
         # (recomputed with the same launches as the timed step: a wave's summation order depends on its index within a
         #  launch -- the unit-order rotation of zk_sep_patches.hip -- so another chunking differs in the last bits)
+        # -- on one more step into a matrix that starts as NaN, so that nothing an earlier step left behind can pass
+        full.fill_(float("nan"))
+        step_gather()
+        torch.cuda.synchronize()
         check = torch.empty((n_local, n_poly), dtype=torch.float64, device=dev)
         for c0, c1 in D._chunk_bounds(n_local, args.gather_chunks):
             D.patch_moments_device(plan, patches[c0:c1], out=check[c0:c1])
@@ -283,8 +417,10 @@ def worker(args):
             print(f"[bench] rank {rank}: owners {sums} seen {[bits(full[r * n_local:(r + 1) * n_local]) for r in range(world)]} "
                   f"nan {[int(torch.isnan(full[r * n_local:(r + 1) * n_local]).sum().item()) for r in range(world)]}", file=sys.stderr)
         ok = comm.max_over_ranks(0.0 if ok else 1.0) == 0.0
+        verified = ok
         del check
         fence()
+        dead.enter("all-gather alone (3 passes)", limit)
         t1 = time.perf_counter()
         for _ in range(3):
             comm.allgather_rows(full, 1, n_total, n_poly, n_local, 0, n_local, D._current_stream_ptr(full))
@@ -301,7 +437,8 @@ def worker(args):
                   "GBps_received_per_rank": (world - 1) * n_local * n_poly * 8 / (alone_ms * 1e-3) / 1e9}
 
     in_step = world > 1 and not args.kernel_only_value
-    elapsed, launches, kernel_ms = (el_gather, l_gather, ms_gather) if in_step else (el_kernel, l_kernel, ms_kernel)
+    elapsed, launches, kernel_ms, spread = ((el_gather, l_gather, ms_gather, spread_gather) if in_step
+                                            else (el_kernel, l_kernel, ms_kernel, spread_kernel))
 
     # ---- the line's contract keys are complete here; the side sections below only add to it -----------------------------
     ms_per_step = elapsed / args.steps * 1e3
@@ -326,40 +463,46 @@ def worker(args):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": rl.HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / rl.HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_ms": kernel_ms / args.steps, "launches": launches,
+                     "kernel_ms_min": spread["min"], "kernel_ms_median": spread["median"], "kernel_ms_max": spread["max"],
+                     "frac_at_median": n_local * per_patch / (spread["median"] * 1e-3) / 1e9 / rl.HBM_PEAK_GBS,
                      "algorithmic_bytes_per_patch": per_patch, "patches_per_step": n_local},
         "kernel_only_patches_per_s": n_total / (ms_kernel / args.steps * 1e-3),
     }
     if gather is not None:
         result["allgather"] = gather
+    if not verified:
+        # a `value` whose gathered matrix is wrong is not a measurement: keep what was timed under another name, say why,
+        # and leave non-zero (every rank takes this branch: `verified` went through max_over_ranks)
+        result["value_unverified"], result["value"] = result["value"], None
+        result["unmeasured"] = "all-gather verification failed (see allgather.verified / own_block_equals_recomputation)"
+        dead.result = result
+        dead.fire("the gathered moment matrix differs from its owners' blocks", 4)
+    dead.result = result            # from here on a stalled or failed side section still delivers the contract keys
 
-    # N > 1: the side sections run collectives nobody here could rehearse on real links.  If one of them stalls, rank 0 still
-    # delivers the line it already has (and says so), and every rank leaves.
-    watchdog = None
-    if world > 1 and not args.only_timed_loop:
-        import threading
-        limit = float(os.environ.get("ZK_BENCH_SIDE_TIMEOUT", "420"))
-
-        def give_up():
-            if rank == 0:
-                result["side_sections"] = f"not finished within {limit:.0f} s; omitted"
-                os.write(json_fd, (json.dumps(result) + "\n").encode())
-            os._exit(0)
-
-        watchdog = threading.Timer(limit, give_up)                      # the ranks left the same barrier a moment ago: same deadline
-        watchdog.daemon = True
-        watchdog.start()
-
+    # N > 1: every side section runs collectives.  A section that fails on one rank cannot be skipped by that rank alone
+    # (the others are inside its collectives): the rank says what happened and leaves non-zero, the launcher stops the
+    # others, rank 0 delivers the line it has (Deadman), and the job's exit code is non-zero.  A section that stalls
+    # ends the same way through its phase limit.
     side = {}
     if not args.only_timed_loop and not args.no_clustering:
+        dead.enter("side section: clustering", limit)
         try:
             side["clustering"] = clustering_section(comm, world, dev, mine, n_local, n_poly,
                                                     cpu_sample=0 if (args.no_cpu_baseline or world > 1) else 500000)
-        except Exception as exc:                                     # a side section must not cost the line
-            side["clustering"] = {"error": f"{type(exc).__name__}: {exc}"}
+        except Exception as exc:
+            if world > 1:
+                import traceback
+                traceback.print_exc()
+                dead.fire(f"clustering section raised {type(exc).__name__}: {exc}", 5)
+            side["clustering"] = {"error": f"{type(exc).__name__}: {exc}"}      # one rank: nobody waits for us
     if world > 1 and not args.only_timed_loop:
-        side.update(multi_rank_sections(args, comm, rank, world, dev, plan, z))
-    if watchdog is not None:
-        watchdog.cancel()
+        side.update(multi_rank_sections(args, comm, rank, world, dev, plan, z, dead, limit))
+        bad = [k for k in ("multi_frame", "sharded_maps") if k in side and not side[k].get("verified", True)]
+        if bad:
+            result.update(side)
+            dead.result = result
+            dead.fire(f"verification of {bad} failed", 4)
+    dead.enter("finishing")
 
     if rank != 0:
         if comm is not None:
@@ -449,14 +592,21 @@ def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4, cpu_sample=
 # ---------------------------------------------------------------------------------------------------------
 # configs[3] / configs[4] at N > 1 (every rank takes part; rank 0 reports)
 # ---------------------------------------------------------------------------------------------------------
-def multi_rank_sections(args, comm, rank, world, dev, plan, z):
+def _bits(t):
+    """Wrapping int64 sum of the bit patterns: exact, independent of the reduction order."""
+    import torch
+    return int(t.contiguous().view(torch.int64).sum().item())
+
+
+def multi_rank_sections(args, comm, rank, world, dev, plan, z, dead, limit):
+    import struct
     import numpy as np
     import torch
     from mtflearn_amd import ZPs, distributed as D, roofline as rl
     from mtflearn_amd.synthetic import honeycomb_frame
     out = {}
     K = args.size
-    stream_of = D._current_stream_ptr
+    nan = float("nan")
 
     def fence():
         torch.cuda.synchronize()
@@ -472,42 +622,75 @@ def multi_rank_sections(args, comm, rank, world, dev, plan, z):
         fence()
         return comm.max_over_ranks((time.perf_counter() - t0) / reps)
 
+    def owners_agree(mine_sums, seen_sums_of):
+        """Every rank sends the bit-sums of ITS blocks; every rank compares what arrived with what the owner sent."""
+        n = len(mine_sums)
+        theirs = [struct.unpack(f"{n}q", b) for b in comm.allgather_host(struct.pack(f"{n}q", *mine_sums))]
+        return all(tuple(seen_sums_of(r)) == theirs[r] for r in range(world))
+
     if not args.no_multi_frame:
         # configs[3]: 8 frames of 2048^2 per rank, moments of all 8 x world frames reassembled on every rank
-        per_rank, Hf = 8, args.frame
+        dead.enter("side section: multi_frame (configs[3])", limit)
+        per_rank, Hf = int(os.environ.get("ZK_BENCH_FRAMES_PER_RANK", "8")), args.frame
         n_frames = per_rank * world
         frames = torch.stack([torch.from_numpy(honeycomb_frame(Hf, seed=1000 + rank * per_rank + i)) for i in range(per_rank)]).to(dev)
         full = torch.empty((n_frames, plan.n_poly, Hf, Hf), dtype=torch.float64, device=dev)
         sec = timed(lambda: D.sharded_frames_moments(plan, comm, frames, n_frames, out=full), 2)
         sec_k = timed(lambda: [D.frame_moments_device(plan, frames[i], out=full[rank * per_rank + i]) for i in range(per_rank)], 2)
-        heads = full[:, 0, Hf // 2, Hf // 2]
-        ok = bool(torch.isfinite(heads).all() and (heads != 0).all())
+        # verification as for the patch matrix: a pass into a result that starts as NaN; own frames bit-equal to a
+        # recomputation, every other frame's bit-sum equal to its owner's
+        dead.enter("side section: multi_frame verification", limit)
+        full.fill_(nan)
+        D.sharded_frames_moments(plan, comm, frames, n_frames, out=full)
+        torch.cuda.synchronize()
+        scratch = torch.empty((plan.n_poly, Hf, Hf), dtype=torch.float64, device=dev)
+        own_ok = True
+        for i in range(per_rank):
+            D.frame_moments_device(plan, frames[i], out=scratch)
+            own_ok = own_ok and bool(torch.equal(scratch, full[rank * per_rank + i]))
+        del scratch
+        ok = own_ok and owners_agree([_bits(full[rank * per_rank + i]) for i in range(per_rank)],
+                                     lambda r: [_bits(full[r * per_rank + i]) for i in range(per_rank)])
         out["multi_frame"] = {
             "workload": f"configs[3]: {n_frames} synthetic {Hf}x{Hf} frames, {per_rank} per GPU, dense {K}-px moments, "
                         f"(F, {plan.n_poly}, H, W) reassembled on every rank (frame i gathered while frame i+1 is computed)",
             "positions_per_s_with_allgather": n_frames * Hf * Hf / sec, "s_per_pass_with_allgather": sec,
             "positions_per_s_kernels_only": n_frames * Hf * Hf / sec_k, "s_per_pass_kernels_only": sec_k,
-            "gathered_bytes": full.numel() * 8, "all_blocks_arrived": comm.max_over_ranks(0.0 if ok else 1.0) == 0.0}
+            "gathered_bytes": full.numel() * 8, "own_block_equals_recomputation": comm.max_over_ranks(0.0 if own_ok else 1.0) == 0.0,
+            "verified": comm.max_over_ranks(0.0 if ok else 1.0) == 0.0}
         del frames, full
         torch.cuda.empty_cache()
     if not args.no_maps:
         # configs[4]: one 4096^2 frame, n_max 10, row bands -> fused maps -> the 41 map planes gathered
+        dead.enter("side section: sharded_maps (configs[4])", limit)
+        Hm = int(os.environ.get("ZK_BENCH_MAPS_FRAME", "4096"))
         z10 = ZPs(n_max=10, size=K)
         plan10 = z10._device_plan()
-        big = torch.from_numpy(honeycomb_frame(4096, seed=1)).to(dev)
+        big = torch.from_numpy(honeycomb_frame(Hm, seed=1)).to(dev)
         theta = np.linspace(0, 2 * np.pi, 360, endpoint=False)
         n_c = rl.n_complex(10)
-        res = {}
-        sec = timed(lambda: res.__setitem__("m", D.sharded_frame_maps(plan10, comm, big, n_c, theta=theta,
-                                                                       n_chunks=args.gather_chunks)), 3)
-        rot, ab, mir = res["m"]
-        ok = bool(torch.isfinite(mir[64:-64:512, 64:-64:512]).all())
+        maps = (torch.empty((4, Hm, Hm), dtype=torch.float64, device=dev), torch.empty((n_c, Hm, Hm), dtype=torch.float64, device=dev),
+                torch.empty((Hm, Hm), dtype=torch.float64, device=dev))
+        run = lambda: D.sharded_frame_maps(plan10, comm, big, n_c, theta=theta, n_chunks=args.gather_chunks, out=maps)
+        sec = timed(run, 3)
+        dead.enter("side section: sharded_maps verification", limit)
+        for t in maps:
+            t.fill_(nan)
+        run()
+        torch.cuda.synchronize()
+        band = lambda t, r: t[..., D.shard_bounds(Hm, r, world)[0]:sum(D.shard_bounds(Hm, r, world)[:2]), :]
+        start, count, _ = D.shard_bounds(Hm, rank, world)
+        again = D.frame_maps_device(plan10, big, n_c, theta=theta, row0=start, n_rows=count)
+        own_ok = all(bool(torch.equal(a, band(t, rank))) for a, t in zip(again, maps))
+        del again
+        ok = own_ok and owners_agree([_bits(band(t, rank)) for t in maps], lambda r: [_bits(band(t, r)) for t in maps])
         out["sharded_maps"] = {
-            "workload": "configs[4]: 4096x4096 frame, 32-px, n_max=10 -> rot_maps[2,3,4,6] + 36 |Z_nm| planes + mirror_map(360), "
+            "workload": f"configs[4]: {Hm}x{Hm} frame, 32-px, n_max=10 -> rot_maps[2,3,4,6] + 36 |Z_nm| planes + mirror_map(360), "
                         f"row bands over {world} GPUs, 41 map planes gathered on every rank",
-            "positions_per_s": 4096 * 4096 / sec, "s_per_pass": sec, "gathered_bytes": 41 * 4096 * 4096 * 8,
-            "all_bands_arrived": comm.max_over_ranks(0.0 if ok else 1.0) == 0.0}
-        del big, rot, ab, mir, res
+            "positions_per_s": Hm * Hm / sec, "s_per_pass": sec, "gathered_bytes": 41 * Hm * Hm * 8,
+            "own_block_equals_recomputation": comm.max_over_ranks(0.0 if own_ok else 1.0) == 0.0,
+            "verified": comm.max_over_ranks(0.0 if ok else 1.0) == 0.0}
+        del big, maps
         torch.cuda.empty_cache()
     return out
 

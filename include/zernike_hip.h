@@ -215,6 +215,9 @@ int zk_frame_maps_dev_strided(zk_plan* plan, const void* image_dev, int dtype, i
  */
 int zk_plan_profile(zk_plan* plan, int enable);
 int zk_plan_profile_read(zk_plan* plan, int64_t* launches, double* total_ms);
+/* Same, launch by launch: the first `cap` kernel times (ms, in launch order) since the last read go to ms_out and
+ * their number to *n_out (bench.py: minimum / median / maximum of the timed steps). */
+int zk_plan_profile_read_launches(zk_plan* plan, double* ms_out, int64_t cap, int64_t* n_out);
 
 /*
  * Host staging of the host-buffer entry points (zk_transform_patches / _frame / _points, zk_frame_maps): the
@@ -275,6 +278,38 @@ int zk_comm_world(const zk_comm* comm);
  */
 int zk_allgather_rows(zk_comm* comm, double* full_dev, int64_t n_planes, int64_t height, int64_t width,
                       int64_t rows_per_rank, int64_t row_off, int64_t n_rows, void* hip_stream);
+
+/*
+ * The schedule of zk_allgather_rows as data.  zk_allgather_rows is two parts: this PURE planner (no GPU, no
+ * RCCL, no communicator: callable on any machine) and an executor that hands the list, in order, to RCCL.
+ * One zk_xfer is one RCCL call on the (n_planes, H, W) array seen as a flat run of doubles:
+ *   ZK_XFER_SEND       ncclSend(full + offset, count, peer)
+ *   ZK_XFER_RECV       ncclRecv(full + offset, count, peer)
+ *   ZK_XFER_ALLGATHER  ncclAllGather(send = full + offset, recv = full + offset - rank * count, count per rank); peer -1
+ *   ZK_XFER_BCAST      ncclBroadcast(full + offset, in place, count, root = peer)
+ * Entries with the same `group` are issued between one ncclGroupStart / ncclGroupEnd (groups are numbered from 0,
+ * ascending along the list).  Contract of a plan set (what tests/test_comm_plan.py checks for every rank of a world):
+ * within a group the sends of rank a to rank b and the receives of b from a are equally many and pairwise of
+ * equal count IN ORDER (RCCL matches point-to-point calls between two ranks in issue order); a rank's receives
+ * are exactly the other ranks' windows, once each, disjoint from one another and from its own window; collective
+ * entries (ALLGATHER / BCAST) appear on every rank in the same order with the same root and count.
+ * `algo`: ZK_COMM_AUTO (whole equal blocks of one plane -> ALLGATHER, else P2P), ZK_COMM_P2P, ZK_COMM_ALLGATHER
+ * (falls back to P2P when the blocks are not whole and equal), ZK_COMM_BCAST.
+ * Writes at most `cap` entries to `out` (may be NULL with cap 0) and the number the plan HAS to *n_out.
+ */
+typedef struct zk_xfer {
+  int32_t op;     /* ZK_XFER_* */
+  int32_t peer;   /* destination (SEND), source (RECV), root (BCAST), -1 (ALLGATHER) */
+  int32_t group;  /* ncclGroupStart / End bracket this entry belongs to */
+  int32_t plane;  /* plane index the run lies in (information only; offset already includes it) */
+  int64_t offset; /* first element, in doubles from full_dev */
+  int64_t count;  /* elements */
+} zk_xfer;
+enum { ZK_XFER_SEND = 1, ZK_XFER_RECV = 2, ZK_XFER_ALLGATHER = 3, ZK_XFER_BCAST = 4 };
+enum { ZK_COMM_AUTO = 0, ZK_COMM_P2P = 1, ZK_COMM_ALLGATHER = 2, ZK_COMM_BCAST = 3 };
+#define ZK_COMM_PLANES_PER_GROUP 16
+int zk_allgather_rows_plan(int rank, int world, int64_t n_planes, int64_t height, int64_t width, int64_t rows_per_rank,
+                           int64_t row_off, int64_t n_rows, int algo, zk_xfer* out, int64_t cap, int64_t* n_out);
 int zk_comm_join(zk_comm* comm, void* hip_stream);
 /* Blocking all-gather of the same number of host bytes from every rank (timings, checksums, the k x D sums of a sharded
  * k-means step; doubles as a barrier).  Up to 64 MiB per rank. */
@@ -338,12 +373,15 @@ int zk_project_dev(int device, const double* X_dev, int64_t n_rows, int n_featur
  *   gmm_lbs(X, n)      reference clustering/_clustering_functions.py:25-33 (sklearn GaussianMixture(n, type).fit(X).predict(X))
  * zk_rows = a float64 matrix (N, D), D <= 127, resident on one device together with the work buffers of these passes.
  * Every pass over the matrix is one call here; what happens between passes (random draws, centre updates, D x D Cholesky
- * factors, convergence tests) is scikit-learn's control flow, restated by the caller (mtflearn_amd/features/consumers.py).
+ * factors, convergence tests) is scikit-learn's control flow, restated by the caller (mtflearn_amd/clustering.py).
  * Results do not depend on scheduling: per-workgroup partial sums are reduced in a fixed order.
  * ------------------------------------------------------------------------------------------------------ */
 typedef struct zk_rows zk_rows;
 int zk_rows_create(int device, const double* X_host, int64_t n_rows, int n_features, zk_rows** out); /* uploads a copy */
-int zk_rows_adopt(int device, const double* X_dev, int64_t n_rows, int n_features, zk_rows** out);   /* borrows X_dev */
+/* borrows X_dev (the caller keeps it alive and unchanged for the object's lifetime).  The passes run on a stream of the
+ * object's own; zk_rows_adopt therefore waits (hipDeviceSynchronize) for whatever is still writing X_dev -- e.g. an
+ * asynchronous zk_transform_patches_dev on the caller's stream -- before it returns. */
+int zk_rows_adopt(int device, const double* X_dev, int64_t n_rows, int n_features, zk_rows** out);
 int zk_rows_destroy(zk_rows* rows);
 const double* zk_rows_data(const zk_rows* rows);                 /* the device matrix */
 /* Column means and population variances (two passes, as numpy.mean / numpy.var); the means become the centring shift of

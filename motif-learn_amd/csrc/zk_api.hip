@@ -67,22 +67,41 @@ extern "C" int zk_plan_profile(zk_plan* p, int enable) {
   return 0;
 }
 
-extern "C" int zk_plan_profile_read(zk_plan* p, int64_t* launches, double* total_ms) {
-  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
-  ZK_ON_PLAN_DEVICE(p);
+// resolves the recorded event pairs; the first `cap` per-launch times go to ms_out (may be NULL)
+static int prof_drain(zk_plan* p, double* ms_out, int64_t cap, int64_t* n_written) {
+  int64_t w = 0;
   for (size_t k = 0; k + 1 < p->ev_used; k += 2) {
     ZK_HIP(hipEventSynchronize(p->ev_pool[k + 1]));
     float ms = 0.f;
     ZK_HIP(hipEventElapsedTime(&ms, p->ev_pool[k], p->ev_pool[k + 1]));
     p->prof_ms += ms;
     p->prof_launches += 1;
+    if (ms_out && w < cap) ms_out[w++] = (double)ms;
   }
   p->ev_used = 0;
+  if (n_written) *n_written = w;
+  return 0;
+}
+
+extern "C" int zk_plan_profile_read(zk_plan* p, int64_t* launches, double* total_ms) {
+  if (!p) return zk_fail(ZK_E_BADARG, "null plan");
+  ZK_ON_PLAN_DEVICE(p);
+  const int rc = prof_drain(p, nullptr, 0, nullptr);
+  if (rc) return rc;
   if (launches) *launches = p->prof_launches;
   if (total_ms) *total_ms = p->prof_ms;
   p->prof_launches = 0;
   p->prof_ms = 0.0;
   return 0;
+}
+
+extern "C" int zk_plan_profile_read_launches(zk_plan* p, double* ms_out, int64_t cap, int64_t* n_out) {
+  if (!p || !n_out || cap < 0 || (cap > 0 && !ms_out)) return zk_fail(ZK_E_BADARG, "bad arguments");
+  ZK_ON_PLAN_DEVICE(p);
+  const int rc = prof_drain(p, ms_out, cap, n_out);
+  p->prof_launches = 0;
+  p->prof_ms = 0.0;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------

@@ -793,6 +793,9 @@ extern "C" int zk_rows_adopt(int device, const double* X_dev, int64_t N, int D, 
   int rc = rows_args(X_dev, N, D, out);
   if (rc) return rc;
   ZK_ON_DEVICE(device);
+  // every pass runs on the object's own non-blocking stream, which is not ordered against whatever stream is still
+  // writing the matrix (zk_transform_patches_dev is asynchronous): wait for the producer here, once
+  ZK_HIP(hipDeviceSynchronize());
   return rows_new(device, X_dev, N, D, false, out);
 }
 

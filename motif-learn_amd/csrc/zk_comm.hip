@@ -226,6 +226,10 @@ extern "C" int zk_comm_init_file(int device, int rank, int world, const char* pa
   char id[ZK_COMM_ID_BYTES];
   const std::string p(path);
   if (rank == 0) {
+    // a file a dead earlier run left behind must not be taken for this run's id: remove it before anything else.  (A peer
+    // can still read it in the instant before this line runs; callers close that window by naming the file per run, as
+    // bench.py does with the launcher's pid and port.)
+    (void)unlink(p.c_str());
     int rc = zk_comm_unique_id(id);
     if (rc) return rc;
     const std::string tmp = p + ".tmp";
@@ -238,10 +242,15 @@ extern "C" int zk_comm_init_file(int device, int rank, int world, const char* pa
     }
   } else {
     const double t_end = now_s() + timeout_s;
+    // rank 0 may have published up to timeout_s before this rank arrived (it waits in ncclCommInitRank); anything older
+    // is a leftover of another run
+    const time_t oldest = time(nullptr) - (time_t)timeout_s - 2;
     for (;;) {
       FILE* f = fopen(p.c_str(), "rb");
       if (f) {
-        const size_t k = fread(id, 1, sizeof id, f);
+        struct stat st;
+        const bool fresh = fstat(fileno(f), &st) == 0 && st.st_mtime >= oldest;
+        const size_t k = fresh ? fread(id, 1, sizeof id, f) : 0;
         fclose(f);
         if (k == sizeof id) break;
       }
@@ -277,7 +286,18 @@ extern "C" int zk_comm_init_tcp(int device, int rank, int world, const char* hos
       sockaddr_in a = {};
       a.sin_family = AF_INET;
       a.sin_port = htons((uint16_t)port);
-      a.sin_addr.s_addr = htonl(INADDR_ANY);
+      // listen on the address the peers were told to use, not on every interface
+      if (inet_pton(AF_INET, host, &a.sin_addr) != 1) {
+        addrinfo hints = {}, *res = nullptr;
+        hints.ai_family = AF_INET;
+        hints.ai_socktype = SOCK_STREAM;
+        if (getaddrinfo(host, nullptr, &hints, &res) != 0 || !res) {
+          close(ls);
+          return zk_fail(ZK_E_COMM, std::string("cannot resolve ") + host);
+        }
+        a.sin_addr = ((sockaddr_in*)res->ai_addr)->sin_addr;
+        freeaddrinfo(res);
+      }
       if (bind(ls, (sockaddr*)&a, sizeof a) != 0 || listen(ls, world) != 0) {
         const std::string why = strerror(errno);
         close(ls);
@@ -352,15 +372,80 @@ inline void window_of(int r, int64_t H, int64_t rpr, int64_t row_off, int64_t n_
   *hi = z;
 }
 
+int check_rows_args(int rank, int world, int64_t n_planes, int64_t H, int64_t W, int64_t rpr, int64_t row_off,
+                    int64_t n_rows) {
+  if (world < 1 || rank < 0 || rank >= world) return zk_fail(ZK_E_BADARG, "need 0 <= rank < world");
+  if (n_planes < 0 || H < 0 || W < 0 || rpr < 0 || row_off < 0 || n_rows < 0)
+    return zk_fail(ZK_E_BADARG, "negative extent");
+  if (rpr * (int64_t)world < H) return zk_fail(ZK_E_BADARG, "rows_per_rank * world does not cover the rows");
+  if (row_off + n_rows > rpr) return zk_fail(ZK_E_BADARG, "window exceeds the block");
+  return 0;
+}
+
+// The schedule.  `emit(op, peer, group, plane, offset, count)` is called once per RCCL call, in issue order.
+template <class Emit>
+void plan_rows(int rank, int world, int64_t n_planes, int64_t H, int64_t W, int64_t rpr, int64_t row_off, int64_t n_rows,
+               int algo, Emit&& emit) {
+  if (world == 1 || n_planes == 0 || H == 0 || W == 0 || n_rows == 0) return;
+  const int64_t plane = H * W;
+  const bool whole_equal = n_planes == 1 && row_off == 0 && n_rows == rpr && rpr * (int64_t)world == H;
+  if (algo == ZK_COMM_AUTO) algo = whole_equal ? ZK_COMM_ALLGATHER : ZK_COMM_P2P;
+  if (algo == ZK_COMM_ALLGATHER && !whole_equal) algo = ZK_COMM_P2P;
+  if (algo == ZK_COMM_ALLGATHER) {
+    emit(ZK_XFER_ALLGATHER, -1, 0, 0, (int64_t)rank * rpr * W, rpr * W);
+    return;
+  }
+  int64_t my_lo, my_hi;
+  window_of(rank, H, rpr, row_off, n_rows, &my_lo, &my_hi);
+  for (int64_t j = 0; j < n_planes; ++j) {
+    // at most ZK_COMM_PLANES_PER_GROUP planes (that many sends + receives per peer) per group launch
+    const int group = (int)(j / ZK_COMM_PLANES_PER_GROUP);
+    const int64_t base = j * plane;
+    if (algo == ZK_COMM_BCAST) {
+      for (int owner = 0; owner < world; ++owner) {
+        int64_t lo, hi;
+        window_of(owner, H, rpr, row_off, n_rows, &lo, &hi);
+        if (hi > lo) emit(ZK_XFER_BCAST, owner, group, (int)j, base + lo * W, (hi - lo) * W);
+      }
+      continue;
+    }
+    for (int step = 1; step < world; ++step) {
+      // staggered peer order: at step s every rank sends to rank + s and receives from rank - s
+      const int to = (rank + step) % world, from = (rank - step + world) % world;
+      if (my_hi > my_lo) emit(ZK_XFER_SEND, to, group, (int)j, base + my_lo * W, (my_hi - my_lo) * W);
+      int64_t lo, hi;
+      window_of(from, H, rpr, row_off, n_rows, &lo, &hi);
+      if (hi > lo) emit(ZK_XFER_RECV, from, group, (int)j, base + lo * W, (hi - lo) * W);
+    }
+  }
+}
+
 }  // namespace
 
+extern "C" int zk_allgather_rows_plan(int rank, int world, int64_t n_planes, int64_t H, int64_t W, int64_t rpr,
+                                      int64_t row_off, int64_t n_rows, int algo, zk_xfer* out, int64_t cap, int64_t* n_out) {
+  if (!n_out) return zk_fail(ZK_E_BADARG, "n_out is null");
+  *n_out = 0;
+  if (algo < ZK_COMM_AUTO || algo > ZK_COMM_BCAST) return zk_fail(ZK_E_BADARG, "unknown algo");
+  if (cap < 0 || (cap > 0 && !out)) return zk_fail(ZK_E_BADARG, "bad output list");
+  const int rc = check_rows_args(rank, world, n_planes, H, W, rpr, row_off, n_rows);
+  if (rc) return rc;
+  int64_t n = 0;
+  plan_rows(rank, world, n_planes, H, W, rpr, row_off, n_rows, algo,
+            [&](int op, int peer, int group, int plane, int64_t offset, int64_t count) {
+              if (n < cap) out[n] = zk_xfer{op, peer, group, plane, offset, count};
+              ++n;
+            });
+  *n_out = n;
+  return 0;
+}
+
+// The executor: the planner's list, in order, handed to RCCL on the communicator's stream.
 extern "C" int zk_allgather_rows(zk_comm* c, double* full, int64_t n_planes, int64_t H, int64_t W, int64_t rpr,
                                  int64_t row_off, int64_t n_rows, void* hip_stream) {
   if (!c) return zk_fail(ZK_E_BADARG, "null communicator");
-  if (n_planes < 0 || H < 0 || W < 0 || rpr < 0 || row_off < 0 || n_rows < 0)
-    return zk_fail(ZK_E_BADARG, "negative extent");
-  if (rpr * (int64_t)c->world < H) return zk_fail(ZK_E_BADARG, "rows_per_rank * world does not cover the rows");
-  if (row_off + n_rows > rpr) return zk_fail(ZK_E_BADARG, "window exceeds the block");
+  int rc = check_rows_args(c->rank, c->world, n_planes, H, W, rpr, row_off, n_rows);
+  if (rc) return rc;
   if (n_planes == 0 || H == 0 || W == 0 || n_rows == 0) return 0;
   if (!full) return zk_fail(ZK_E_BADARG, "null device pointer");
   ZK_ON_DEVICE(c->device);
@@ -368,47 +453,38 @@ extern "C" int zk_allgather_rows(zk_comm* c, double* full, int64_t n_planes, int
   ZK_HIP(hipEventRecord(c->ev_in, producer));
   ZK_HIP(hipStreamWaitEvent(c->stream, c->ev_in, 0));
   if (c->world == 1) return 0;
-  const long long plane = (long long)H * W;
-  const bool whole_equal = n_planes == 1 && row_off == 0 && n_rows == rpr && rpr * (int64_t)c->world == H;
-  int algo = c->algo;
-  if (algo == 0) algo = whole_equal ? 2 : 1;
-  if (algo == 2 && !whole_equal) algo = 1;
-  if (algo == 2) {
-    ZK_NCCL(g_rccl.AllGather(full + (long long)c->rank * rpr * W, full, (size_t)(rpr * W), ncclFloat64, c->nccl, c->stream));
-    return 0;
-  }
-  ZK_NCCL(g_rccl.GroupStart());
   ncclResult_t r = ncclSuccess;
-  int64_t my_lo, my_hi;
-  window_of(c->rank, H, rpr, row_off, n_rows, &my_lo, &my_hi);
-  for (int64_t j = 0; j < n_planes && r == ncclSuccess; ++j) {
-    if (j > 0 && j % 16 == 0) {  // at most 16 planes (16 sends + 16 receives per peer) per group launch
-      r = g_rccl.GroupEnd();
-      if (r == ncclSuccess) r = g_rccl.GroupStart();
-      if (r != ncclSuccess) return rccl_fail(r, "grouped exchange (plane batch)");
-    }
-    double* pl = full + j * plane;
-    if (algo == 3) {
-      for (int owner = 0; owner < c->world && r == ncclSuccess; ++owner) {
-        int64_t lo, hi;
-        window_of(owner, H, rpr, row_off, n_rows, &lo, &hi);
-        if (hi > lo) r = g_rccl.Broadcast(pl + lo * W, pl + lo * W, (size_t)((hi - lo) * W), ncclFloat64, owner, c->nccl, c->stream);
-      }
-      continue;
-    }
-    for (int step = 1; step < c->world && r == ncclSuccess; ++step) {
-      // staggered peer order: at step s every rank sends to rank + s and receives from rank - s
-      const int to = (c->rank + step) % c->world, from = (c->rank - step + c->world) % c->world;
-      int64_t lo, hi;
-      if (my_hi > my_lo) r = g_rccl.Send(pl + my_lo * W, (size_t)((my_hi - my_lo) * W), ncclFloat64, to, c->nccl, c->stream);
-      window_of(from, H, rpr, row_off, n_rows, &lo, &hi);
-      if (hi > lo && r == ncclSuccess)
-        r = g_rccl.Recv(pl + lo * W, (size_t)((hi - lo) * W), ncclFloat64, from, c->nccl, c->stream);
+  int open_group = -1;  // the group bracket currently open (collective-only plans of one entry need none)
+  const char* failed = "";
+  plan_rows(c->rank, c->world, n_planes, H, W, rpr, row_off, n_rows, c->algo,
+            [&](int op, int peer, int group, int, int64_t offset, int64_t count) {
+              if (r != ncclSuccess) return;
+              if (op != ZK_XFER_ALLGATHER && group != open_group) {
+                if (open_group >= 0) r = g_rccl.GroupEnd();
+                if (r == ncclSuccess) r = g_rccl.GroupStart();
+                if (r != ncclSuccess) {
+                  failed = "grouped exchange (plane batch)";
+                  return;
+                }
+                open_group = group;
+              }
+              double* at = full + offset;
+              switch (op) {
+                case ZK_XFER_SEND: r = g_rccl.Send(at, (size_t)count, ncclFloat64, peer, c->nccl, c->stream); break;
+                case ZK_XFER_RECV: r = g_rccl.Recv(at, (size_t)count, ncclFloat64, peer, c->nccl, c->stream); break;
+                case ZK_XFER_BCAST: r = g_rccl.Broadcast(at, at, (size_t)count, ncclFloat64, peer, c->nccl, c->stream); break;
+                default: r = g_rccl.AllGather(at, at - (int64_t)c->rank * count, (size_t)count, ncclFloat64, c->nccl, c->stream);
+              }
+              if (r != ncclSuccess) failed = "grouped exchange";
+            });
+  if (open_group >= 0) {  // always close the bracket, also after a failed call inside it
+    const ncclResult_t r_end = g_rccl.GroupEnd();
+    if (r == ncclSuccess && r_end != ncclSuccess) {
+      r = r_end;
+      failed = "ncclGroupEnd";
     }
   }
-  const ncclResult_t r_end = g_rccl.GroupEnd();
-  if (r != ncclSuccess) return rccl_fail(r, "grouped exchange");
-  if (r_end != ncclSuccess) return rccl_fail(r_end, "ncclGroupEnd");
+  if (r != ncclSuccess) return rccl_fail(r, failed);
   return 0;
 }
 

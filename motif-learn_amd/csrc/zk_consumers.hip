@@ -135,8 +135,11 @@ extern "C" int zk_gram(int device, const double* X_host, int64_t N, int D, doubl
 extern "C" int zk_project(int device, const void* X_dev, int64_t N, int D, const double* mean_host, const double* comp_host, int k,
                           double* Y_host, int free_x) {
   if (!X_dev || !mean_host || !comp_host || !Y_host) return zk_fail(ZK_E_BADARG, "null pointer");
-  if (N <= 0 || D <= 0 || k <= 0 || k > 16) return zk_fail(ZK_E_BADARG, "need N, D > 0 and 1 <= k <= 16 components");
   ZK_ON_DEVICE(device);
+  if (N <= 0 || D <= 0 || k <= 0 || k > 16) {
+    if (free_x) (void)hipFree((void*)X_dev);  // free_x holds on every exit path once X_dev is known
+    return zk_fail(ZK_E_BADARG, "need N, D > 0 and 1 <= k <= 16 components");
+  }
   double *d_t = nullptr, *d_y = nullptr;
   hipError_t e = hipMalloc((void**)&d_t, (size_t)(D + (size_t)k * D) * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&d_y, (size_t)N * k * sizeof(double));

@@ -18,7 +18,18 @@ ZK_F32, ZK_F64 = 0, 1
 ZK_U8, ZK_U16, ZK_I16 = 2, 3, 4   # host-buffer entry points only: widened to float32 on the device (exact)
 PATH_AUTO, PATH_GENERIC, PATH_FOLDED, PATH_SEPARABLE, PATH_STREAM = 0, 1, 2, 3, 4
 OP_POINTS, OP_MAPS = 1, 2
+XFER_SEND, XFER_RECV, XFER_ALLGATHER, XFER_BCAST = 1, 2, 3, 4
+COMM_AUTO, COMM_P2P, COMM_ALLGATHER, COMM_BCAST = 0, 1, 2, 3
+COMM_ALGOS = {"": COMM_AUTO, "auto": COMM_AUTO, "p2p": COMM_P2P, "allgather": COMM_ALLGATHER, "bcast": COMM_BCAST}
 PATH_NAMES = {PATH_GENERIC: "generic", PATH_FOLDED: "folded", PATH_SEPARABLE: "separable", PATH_STREAM: "stream"}
+
+
+
+class Xfer(ctypes.Structure):
+    """``zk_xfer``: one RCCL call of the all-gather schedule (include/zernike_hip.h)."""
+    _fields_ = [("op", c_int32), ("peer", c_int32), ("group", c_int32), ("plane", c_int32),
+                ("offset", c_int64), ("count", c_int64)]
+
 
 # MTFLEARN_AMD_LIB: alternative build of the same ABI (e.g. a timing-only ablation variant)
 LIB_PATH = os.environ.get("MTFLEARN_AMD_LIB") or os.path.join(
@@ -74,6 +85,8 @@ SYMBOLS = {
     "zk_comm_rank": (c_int, [c_void_p]),
     "zk_comm_world": (c_int, [c_void_p]),
     "zk_allgather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "zk_allgather_rows_plan": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int,
+                                       POINTER(Xfer), c_int64, POINTER(c_int64)]),
     "zk_comm_join": (c_int, [c_void_p, c_void_p]),
     "zk_comm_allgather_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "zk_autocorr_mean": (c_int, [c_int, c_void_p, c_int, c_int64, c_int64, c_int64, POINTER(c_int32), c_int, c_int,
@@ -122,6 +135,7 @@ SYMBOLS = {
     "zk_device_synchronize": (c_int, [c_int]),
     "zk_plan_profile": (c_int, [c_void_p, c_int]),
     "zk_plan_profile_read": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
+    "zk_plan_profile_read_launches": (c_int, [c_void_p, POINTER(c_double), c_int64, POINTER(c_int64)]),
 }
 
 _lib = None
@@ -307,6 +321,13 @@ class Plan:
         check(self._lib.zk_plan_profile_read(self._h, byref(launches), byref(ms)), "zk_plan_profile_read")
         return launches.value, ms.value
 
+    def profile_read_launches(self, cap=4096):
+        """Per-launch kernel times (ms) recorded since the last read, in launch order."""
+        buf = (c_double * cap)()
+        n = c_int64()
+        check(self._lib.zk_plan_profile_read_launches(self._h, buf, cap, byref(n)), "zk_plan_profile_read_launches")
+        return list(buf[:n.value])
+
     # -- host-buffer entry points --------------------------------------------------------
     def transform_patches(self, patches):
         code = dtype_code(patches.dtype)
@@ -426,6 +447,21 @@ class Plan:
     def release_staging(self):
         """Free the staging buffers the host-buffer entry points have grown (re-created on demand)."""
         check(self._lib.zk_plan_release_staging(self._h), "zk_plan_release_staging")
+
+
+def allgather_rows_plan(rank, world, n_planes, height, width, rows_per_rank, row_off, n_rows, algo=COMM_AUTO):
+    """The schedule ``zk_allgather_rows`` executes on rank ``rank`` of ``world``, as a list of
+    ``(op, peer, group, plane, offset, count)`` tuples in issue order (``zk_allgather_rows_plan``; pure host code)."""
+    lib = load()
+    if isinstance(algo, str):
+        algo = COMM_ALGOS[algo]
+    need = c_int64()
+    args = (int(rank), int(world), int(n_planes), int(height), int(width), int(rows_per_rank), int(row_off), int(n_rows),
+            int(algo))
+    check(lib.zk_allgather_rows_plan(*args, None, 0, byref(need)), "zk_allgather_rows_plan")
+    buf = (Xfer * max(1, need.value))()
+    check(lib.zk_allgather_rows_plan(*args, buf, need.value, byref(need)), "zk_allgather_rows_plan")
+    return [(x.op, x.peer, x.group, x.plane, x.offset, x.count) for x in buf[:need.value]]
 
 
 class Comm:

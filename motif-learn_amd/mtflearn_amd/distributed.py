@@ -29,9 +29,9 @@ import numpy as np
 
 from . import _native
 
-__all__ = ["shard_bounds", "RcclComm", "TorchComm", "DeviceCompute", "patch_moments_device",
+__all__ = ["shard_bounds", "one_gpu_rank_env", "RcclComm", "TorchComm", "DeviceCompute", "patch_moments_device",
            "frame_moments_device", "frame_maps_device", "sharded_patch_moments", "sharded_frame_moments",
-           "sharded_frame_maps", "sharded_frames_moments", "allgather_patch_moments", "allgather_frame_moments"]
+           "sharded_frame_maps", "sharded_frames_moments"]
 
 
 def shard_bounds(n_units: int, rank: int, world: int):
@@ -43,6 +43,22 @@ def shard_bounds(n_units: int, rank: int, world: int):
     start = min(rank * padded, n_units)
     count = min(padded, n_units - start)
     return start, count, padded
+
+
+def one_gpu_rank_env(rank, base=None):
+    """Environment for rank ``rank`` of a REHEARSAL of several RCCL ranks on ONE GPU (a test aid: tests/
+    test_gpu_multirank.py, ``bench.py --gpus N`` with ``ZK_BENCH_ONE_DEVICE=1``).  RCCL refuses two ranks of one
+    communicator on the same device of the same host ("Duplicate GPU detected"); with a different ``NCCL_HOSTID`` per
+    process it takes the ranks for different hosts and connects them through its socket transport on the loopback
+    interface.  The data then moves over TCP instead of xGMI -- timings mean nothing -- but every call of the shipped
+    collective (``ncclSend`` / ``ncclRecv`` groups, ``ncclAllGather``, ``ncclBroadcast`` as ``zk_allgather_rows``
+    issues them) executes in librccl with more than one rank."""
+    import os
+    env = dict(os.environ if base is None else base)
+    env.update(NCCL_HOSTID=f"zk-one-gpu-rank-{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
+               NCCL_SHM_DISABLE="1", NCCL_P2P_DISABLE="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
 
 
 def _chunk_bounds(padded: int, n_chunks: int):
@@ -186,30 +202,79 @@ class RcclComm:
 
 
 class TorchComm:
-    """Same interface on ``torch.distributed`` -- a TEST AID (``gloo`` on CPU tensors for the world-size-2
-    tests, ``gloo`` on GPU tensors to rehearse two ranks on one GPU).  Blocking; ``stream`` is ignored."""
+    """Same interface on ``torch.distributed`` -- a TEST AID (``gloo`` on CPU tensors for the world-size-2 / 3
+    tests, ``gloo`` with GPU tensors staged through the host to rehearse several ranks on one GPU).  Blocking;
+    ``stream`` is ignored.  ``allgather_rows`` executes the SAME schedule as the product: the list
+    ``zk_allgather_rows_plan`` returns for this rank (the planner half of ``zk_allgather_rows``), entry by entry,
+    with ``isend`` / ``irecv`` / ``broadcast`` / ``all_gather_into_tensor`` standing in for the RCCL calls and a
+    wait at every group boundary -- so an error in the window arithmetic, in the pairing of sends and receives or
+    in their order (gloo, like RCCL, matches point-to-point messages between two ranks in issue order) fails the
+    gloo tests.  ``algo``: ``"p2p" | "allgather" | "bcast"`` as ``ZK_COMM_ALGO`` (default: the environment's)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, algo=None):
+        import os
         import torch.distributed as dist
         self._dist, self._group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.algo = _native.COMM_ALGOS.get(os.environ.get("ZK_COMM_ALGO", "") if algo is None else algo, _native.COMM_AUTO)
+        self.calls = 0          # RCCL-call stand-ins executed so far (tests read it)
+
+    def _global(self, r):
+        return r if self._group is None else self._dist.get_global_rank(self._group, r)
 
     def allgather_rows(self, full, n_planes, height, width, rows_per_rank, row_off, n_rows, stream=0):
-        if full.is_cuda:
-            import torch
+        import torch
+        dist = self._dist
+        plan = _native.allgather_rows_plan(self.rank, self.world, n_planes, height, width, rows_per_rank, row_off,
+                                           n_rows, self.algo)
+        if not plan:
+            return
+        if full.numel() != n_planes * height * width or not full.is_contiguous():
+            raise ValueError("the gathered array must be contiguous and hold n_planes * height * width values")
+        on_gpu = full.is_cuda
+        if on_gpu:
             torch.cuda.current_stream(full.device).synchronize()
-        view = full.view(n_planes, height, width)
-        for owner in range(self.world):
-            b0 = owner * rows_per_rank
-            lo = min(b0 + row_off, height)
-            hi = min(b0 + row_off + n_rows, min(b0 + rows_per_rank, height))
-            if hi <= lo:
-                continue
-            piece = view[:, lo:hi, :].contiguous()
-            self._dist.broadcast(piece, src=owner if self._group is None else self._dist.get_global_rank(self._group, owner),
-                                 group=self._group)
-            if owner != self.rank:
-                view[:, lo:hi, :].copy_(piece)
+        flat = full.view(-1)
+        pending, landed = [], []       # requests of the open group; (host buffer, offset) pairs to copy back to the GPU
+
+        def run(seg):                  # the tensor gloo works on: the run itself (CPU) or a host copy of it (GPU)
+            return seg.cpu() if on_gpu else seg
+
+        def flush():
+            for req in pending:
+                req.wait()
+            pending.clear()
+            for buf, off in landed:
+                flat[off:off + buf.numel()].copy_(buf)
+            landed.clear()
+
+        group_now = plan[0][2]
+        for op, peer, group, _plane, off, cnt in plan:
+            if group != group_now:
+                flush()
+                group_now = group
+            seg = flat[off:off + cnt]
+            self.calls += 1
+            if op == _native.XFER_SEND:
+                pending.append(dist.isend(run(seg), self._global(peer), group=self._group))
+            elif op == _native.XFER_RECV:
+                buf = torch.empty(cnt, dtype=full.dtype) if on_gpu else seg
+                pending.append(dist.irecv(buf, self._global(peer), group=self._group))
+                if on_gpu:
+                    landed.append((buf, off))
+            elif op == _native.XFER_BCAST:
+                flush()                # a collective does not overtake the point-to-point calls issued before it
+                buf = run(seg)
+                dist.broadcast(buf, src=self._global(peer), group=self._group)
+                if on_gpu and peer != self.rank:
+                    seg.copy_(buf)
+            else:                      # XFER_ALLGATHER: send = own block, receive = the run of all blocks around it
+                flush()
+                base = off - self.rank * cnt
+                out = torch.empty(cnt * self.world, dtype=full.dtype)
+                dist.all_gather_into_tensor(out, run(seg).clone(), group=self._group)
+                flat[base:base + cnt * self.world].copy_(out)
+        flush()
 
     def join(self, stream=0):
         pass
@@ -302,17 +367,20 @@ def sharded_frame_moments(plan, comm, image, out=None, n_chunks=4):
 
 
 def sharded_frame_maps(plan, comm, image, n_complex, folds=(2, 3, 4, 6), m_unselect=(0, 1), p=2, theta=None,
-                       want_abs=True, n_chunks=4):
+                       want_abs=True, n_chunks=4, out=None):
     """configs[4]: frame -> fused symmetry maps, row bands sharded, the maps (not the moments) gathered:
     ``len(folds) + n_complex + 1`` planes instead of ``n_poly``.  Returns ``(rot, abs, mirror)`` whole-frame
-    tensors (``None`` where not requested) on every rank."""
+    tensors (``None`` where not requested) on every rank; ``out = (rot, abs, mirror)`` supplies them."""
     compute = _as_compute(plan)
     h, w = image.shape
     start, count, padded = shard_bounds(h, comm.rank, comm.world)
     n_folds = len(folds) if folds is not None else 0
-    rot = compute.empty((n_folds, h, w), image) if n_folds else None
-    ab = compute.empty((n_complex, h, w), image) if want_abs else None
-    mir = compute.empty((h, w), image) if theta is not None else None
+    if out is not None:
+        rot, ab, mir = out
+    else:
+        rot = compute.empty((n_folds, h, w), image) if n_folds else None
+        ab = compute.empty((n_complex, h, w), image) if want_abs else None
+        mir = compute.empty((h, w), image) if theta is not None else None
     full = (rot, ab, mir)
     stream = compute.stream(image)
     for c0, c1 in _chunk_bounds(padded, n_chunks):
@@ -343,33 +411,3 @@ def sharded_frames_moments(plan, comm, frames_local, n_frames, out=None):
         comm.allgather_rows(full, 1, n_frames, compute.n_poly * h * w, padded, i, 1, stream)
     comm.join(stream)
     return full
-
-
-# ---------------------------------------------------------------------------------------------------------
-# round-1 helpers on torch.distributed (kept for callers that already run a process group; test aid)
-# ---------------------------------------------------------------------------------------------------------
-def allgather_patch_moments(local, n_total=None, group=None, out=None):
-    """All-gather equal-sized ``(padded, n_poly)`` blocks into ``(world*padded, n_poly)`` on every
-    rank (one collective), trimmed to ``n_total`` rows when given."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    if out is None:
-        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
-                          device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    return out if n_total is None else out[:n_total]
-
-
-def allgather_frame_moments(local, height=None, group=None):
-    """All-gather row bands ``(n_poly, padded_rows, W)`` into the reference layout
-    ``(n_poly, H, W)`` on every rank (one collective + a strided view; ``.contiguous()`` it if a
-    packed array is required)."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    n_poly, rows, width = local.shape
-    slab = torch.empty((world * n_poly, rows, width), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(slab, local.contiguous(), group=group)
-    full = slab.view(world, n_poly, rows, width).permute(1, 0, 2, 3).reshape(n_poly, world * rows, width)
-    return full if height is None else full[:, :height]

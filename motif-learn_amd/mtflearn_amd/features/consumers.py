@@ -11,8 +11,8 @@ scikit-learn is a dependency of the reference and of this package, so parity is 
 usual case: millions of patches x 45 moments); for smaller inputs it uses an SVD of the centred matrix, which this
 routine does not imitate -- same subspace and signs, last digits may differ.
 
-The reference's clustering wrappers (``kmeans_lbs`` / ``gmm_lbs``) live in ``mtflearn_amd.clustering``; ``ForceGraph8`` (a
-sequential numba layout optimiser) is not rebuilt.
+The reference's clustering wrappers (``kmeans_lbs`` / ``gmm_lbs``) live in ``mtflearn_amd.clustering``, ``ForceGraph8`` in
+``mtflearn_amd.manifold``.
 """
 from __future__ import annotations
 
@@ -93,17 +93,24 @@ def pca(X, n_components=2, reconstruct=False, comm=None):
     x_dev = c_void_p()
     _native.check(lib.zk_gram(dev, X.ctypes.data_as(POINTER(c_double)), n, d, gram.ctypes.data_as(POINTER(c_double)),
                               byref(x_dev)), "zk_gram")
-    mean, vt, _ = _covariance_eigh(gram, n)
-    out = _native.pinned.empty((n, k))
-    done = 0
-    while done < k:                                                          # at most 16 components per launch
-        kk = min(16, k - done)
-        comp = np.ascontiguousarray(vt[done:done + kk])
-        part = out if kk == k else np.empty((n, kk), dtype=np.float64)
-        _native.check(lib.zk_project(dev, x_dev, n, d, mean.ctypes.data_as(POINTER(c_double)),
-                                     comp.ctypes.data_as(POINTER(c_double)), kk, part.ctypes.data_as(POINTER(c_double)),
-                                     int(done + kk == k)), "zk_project")
-        if part is not out:
-            out[:, done:done + kk] = part
-        done += kk
-    return out
+    freed = False                                                            # the last zk_project call frees x_dev
+    try:
+        mean, vt, _ = _covariance_eigh(gram, n)
+        out = _native.pinned.empty((n, k))
+        done = 0
+        while done < k:                                                      # at most 16 components per launch
+            kk = min(16, k - done)
+            comp = np.ascontiguousarray(vt[done:done + kk])
+            part = out if kk == k else np.empty((n, kk), dtype=np.float64)
+            last = done + kk == k
+            freed = last                                                     # zk_project frees it on every exit path when asked to
+            _native.check(lib.zk_project(dev, x_dev, n, d, mean.ctypes.data_as(POINTER(c_double)),
+                                         comp.ctypes.data_as(POINTER(c_double)), kk, part.ctypes.data_as(POINTER(c_double)),
+                                         int(last)), "zk_project")
+            if part is not out:
+                out[:, done:done + kk] = part
+            done += kk
+        return out
+    finally:
+        if not freed and x_dev.value:                                        # eigh / allocation / an earlier chunk failed
+            lib.zk_device_free(dev, x_dev)

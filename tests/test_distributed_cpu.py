@@ -1,6 +1,6 @@
-"""N>1 path on CPU: world_size-2 (and 3) gloo processes run the product's sharded drivers
-(``mtflearn_amd.distributed.sharded_*``) with the test-aid communicator ``TorchComm`` and an
-oracle-backed stand-in for the kernels.  What is under test is everything around the kernels: block and
+"""N>1 path on CPU: world_size-2 (3, 4) gloo processes run the product's sharded drivers
+(``mtflearn_amd.distributed.sharded_*``) with the test-aid communicator ``TorchComm`` -- which executes the product's
+own all-gather schedule (``zk_allgather_rows_plan``) on gloo -- and an oracle-backed stand-in for the kernels.  What is under test is everything around the kernels: block and
 chunk bounds (ragged tails, empty ranks), in-place placement of a rank's block inside the full result, the
 windows every collective call moves, and that every rank ends with the complete, correct array.  The
 arithmetic itself is the GPU suite's business (tests/test_gpu_parity.py)."""
@@ -96,7 +96,7 @@ def _inputs():
 THETA = np.linspace(0, 2 * np.pi, 24, endpoint=False)
 
 
-def _worker(rank, world, port, tmpdir):
+def _worker(rank, world, port, tmpdir, algo):
     for p in (ROOT, os.path.join(ROOT, "motif-learn_amd")):
         sys.path.insert(0, p)
     import torch
@@ -106,7 +106,7 @@ def _worker(rank, world, port, tmpdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        comm = D.TorchComm()
+        comm = D.TorchComm(algo=algo)
         oc = _OracleCompute(4, 8)
         patches, frame, frames = _inputs()
         n_c = sum(n // 2 + 1 for n in range(5))
@@ -122,6 +122,7 @@ def _worker(rank, world, port, tmpdir):
         start, count, _ = D.shard_bounds(5, rank, world)
         fullb = D.sharded_frames_moments(oc, comm, torch.from_numpy(frames[start:start + count]), 5)
         np.save(os.path.join(tmpdir, f"frames_{rank}.npy"), fullb.numpy())
+        assert comm.calls > 0                                # the planner's entries were what moved the data
         # the timing reduction of bench.py
         assert comm.max_over_ranks(float(rank)) == float(world - 1)
         comm.barrier()
@@ -129,11 +130,13 @@ def _worker(rank, world, port, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_drivers_reassemble_everything(tmp_path, world):
+@pytest.mark.parametrize("world,algo", [(2, "auto"), (3, "auto"), (2, "bcast"), (3, "p2p"), (4, "allgather")])
+def test_sharded_drivers_reassemble_everything(tmp_path, world, algo):
+    """The drivers at world 2 - 4 on gloo.  TorchComm executes the list of zk_allgather_rows_plan -- the schedule the
+    RCCL executor runs -- so the windows, the pairing and the order of the shipped collective are what is tested."""
     import torch.multiprocessing as mp
     from oracle import zernike_oracle as zo
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), algo), nprocs=world, join=True)
     n, m, basis = zo.zernike_basis(4, 8)
     patches, frame, frames = _inputs()
     ref_p = zo.moments_patches(patches, basis)

@@ -20,6 +20,13 @@ def _zps(n_max, size):
         return ZPs(n_max, size)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _torch():
     import torch
     assert torch.cuda.is_available()
@@ -144,7 +151,7 @@ def test_rccl_communicator_world_one(tmp_path, rendezvous):
         comm = D.RcclComm(0, 0, 1, path=str(tmp_path / "id"))
         assert not os.path.exists(tmp_path / "id")                           # rank 0 removes it after the join
     elif rendezvous == "tcp":
-        comm = D.RcclComm(0, 0, 1, port=29641)
+        comm = D.RcclComm(0, 0, 1, port=_free_port())
     else:
         comm = D.RcclComm(0, 0, 1, unique_id=_native.Comm.unique_id())
     try:
@@ -259,7 +266,7 @@ def test_two_process_rendezvous_reaches_rccl(tmp_path, rendezvous):
         "    print('CONNECTED')\n"
         "except RuntimeError as exc:\n"
         "    print('ERROR', exc)\n")
-    target = str(tmp_path / "id") if rendezvous == "file" else "29655"
+    target = str(tmp_path / "id") if rendezvous == "file" else str(_free_port())
     procs = [subprocess.Popen([sys.executable, "-c", code, os.path.join(ROOT, "motif-learn_amd"), str(r), rendezvous, target],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (0, 1)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
