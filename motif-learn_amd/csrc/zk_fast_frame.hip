@@ -33,16 +33,8 @@ __global__ __launch_bounds__(256) void zk_frame_fold_kernel(
   const int tile_rows = K + 3;
   const int tile_elems = tile_rows * tile_pitch;
 
-  // ---- stage the zero-padded tile as float64 ------------------------------------------
-  for (int e = tid; e < tile_elems; e += 256) {
-    const int tr = e / tile_pitch;
-    const int tc = e - tr * tile_pitch;
-    const int ii = i0 - ea + tr;
-    const int kk = k0 - ea + tc;
-    double v = 0.0;
-    if (ii >= 0 && ii < H && kk >= 0 && kk < W) v = (double)img[(long long)ii * W + kk];
-    tile[e] = v;
-  }
+  zk_stage_tile(tile, img, H, W, i0 - ea, k0 - ea, tile_rows, tile_pitch);
+  (void)tile_elems;
   __syncthreads();
 
   // ---- accumulate -----------------------------------------------------------------------

@@ -128,6 +128,37 @@ __device__ __forceinline__ const ZK_CONST T* zk_const(const T* p) {
   return (const ZK_CONST T*)p;
 }
 
+// Dense kernels: stage the zero-padded tile (tile_rows x tile_pitch, frame rows i_first.., columns k_first..) into LDS as
+// float64.  256 threads; wave w takes tile rows w, w + 4, ..., lane l the columns l, l + 64, ...  The loads of
+// ZK_STAGE_BATCH rows are issued before the first is converted: one exposed memory latency per batch.  (Written as
+// load - convert - store per element, the compiler waits for every single load: ~20 serial round trips per wave, a quarter of
+// a (32, 8) workgroup's life with the SIMDs half empty -- profiles/r03_strip_notes.txt.)
+#ifndef ZK_STAGE_BATCH
+#define ZK_STAGE_BATCH 10
+#endif
+template <typename T>
+__device__ __forceinline__ void zk_stage_tile(double* __restrict__ tile, const T* __restrict__ img, int H, int W, int i_first,
+                                              int k_first, int tile_rows, int tile_pitch) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int tr0 = wave; tr0 < tile_rows; tr0 += 4 * ZK_STAGE_BATCH) {
+    for (int tc = lane; tc < tile_pitch; tc += 64) {
+      const int kk = k_first + tc;
+      const bool col_ok = kk >= 0 && kk < W;
+      T v[ZK_STAGE_BATCH];
+#pragma unroll
+      for (int b = 0; b < ZK_STAGE_BATCH; ++b) {
+        const int ii = i_first + tr0 + 4 * b;  // (wave-uniform)
+        v[b] = (T)0;
+        if (tr0 + 4 * b < tile_rows && ii >= 0 && ii < H && col_ok) v[b] = img[(long long)ii * W + kk];
+      }
+#pragma unroll
+      for (int b = 0; b < ZK_STAGE_BATCH; ++b)
+        if (tr0 + 4 * b < tile_rows) tile[(tr0 + 4 * b) * tile_pitch + tc] = (double)v[b];
+    }
+  }
+}
+
 // acc[slot] += F_class(slot) * bt[slot] for every slot of the NMAX set; bt is wave-uniform, so
 // its elements arrive through scalar loads and feed v_fma_f64 as SGPR operands.
 template <int NMAX>

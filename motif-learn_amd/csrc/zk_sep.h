@@ -169,6 +169,7 @@ struct zk_sep_tables {
   int n_rows = 0;
   zk_sep_row* d_rows = nullptr;    // [n_rows]
   int32_t* d_cmin = nullptr;       // [K] first quadrant column inside the disk of window row r (Q: none); strip kernel
+  int32_t* d_strip_rows = nullptr; // [K + 1] strip kernel (even K): per frame row n1 | n2 << 8, the column pairs of its two sweeps
   int tile_pitch = 0;
   // fused maps: fold weights + [n_theta][2][kernel_nmax] cos / sin(m theta).  One device table per distinct
   // (folds, m_unselect, theta) option set, kept for the life of the plan (a few KiB each, at most
@@ -427,6 +428,43 @@ struct zk_sep_acc : zk_sep_rows<NMAX, MASK> {
     if constexpr (R::kOO) transform_class<ZK_OO>(tmat, emit);
   }
 };
+
+// Z = T M for TWO accumulator sets at once (strip dense kernel: a lane's two outputs go to the same planes, one row
+// apart): every entry of T is fetched once and feeds two FMAs.  emit(slot, z_a, z_b).
+template <int NMAX, int CLS, int J, typename F>
+__device__ __forceinline__ void zk_sep_transform2_row(const zk_sep_acc<NMAX>& A, const zk_sep_acc<NMAX>& B,
+                                                      const ZK_CONST double* tmat, F&& emit) {
+  using S = zk_sep_set<NMAX>;
+  using P = zk_sep_meta<NMAX>;
+  constexpr int n = S::cls_count(CLS), off = S::cls_begin(CLS);
+  constexpr int rb = P::tab.row_begin[off + J], zn = P::tab.zn[off + J];
+  const ZK_CONST double* tb = tmat + rb;
+  double za = 0.0, zb = 0.0;
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < n; ++i)
+    if (P::tab.deg[off + i] <= zn) {
+      const double t = tb[k++];
+      za = __builtin_fma(t, A.M[off + i], za);
+      zb = __builtin_fma(t, B.M[off + i], zb);
+    }
+  emit(std::integral_constant<int, off + J>{}, za, zb);
+  __builtin_amdgcn_sched_barrier(0);  // (as transform_row: keep the rows' scalar loads from piling up at the top)
+}
+template <int NMAX, int CLS, typename F, int... Js>
+__device__ __forceinline__ void zk_sep_transform2_rows(const zk_sep_acc<NMAX>& A, const zk_sep_acc<NMAX>& B,
+                                                       const ZK_CONST double* tmat, F&& emit, std::integer_sequence<int, Js...>) {
+  (zk_sep_transform2_row<NMAX, CLS, Js>(A, B, tmat, emit), ...);
+}
+template <int NMAX, typename F>
+__device__ __forceinline__ void zk_sep_transform2(const zk_sep_acc<NMAX>& A, const zk_sep_acc<NMAX>& B, const ZK_CONST double* tmat,
+                                                  F&& emit) {
+  using S = zk_sep_set<NMAX>;
+  zk_sep_transform2_rows<NMAX, ZK_EE>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_EE)>{});
+  zk_sep_transform2_rows<NMAX, ZK_OE>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_OE)>{});
+  zk_sep_transform2_rows<NMAX, ZK_EO>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_EO)>{});
+  zk_sep_transform2_rows<NMAX, ZK_OO>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_OO)>{});
+}
 
 template <typename F, int... Is>
 __device__ __forceinline__ void zk_for_each_slot_impl(F&& f, std::integer_sequence<int, Is...>) {

@@ -68,6 +68,7 @@ void zk_sep_free(zk_plan* p) {
   if (t->d_colmap) (void)hipFree(t->d_colmap);
   if (t->d_rows) (void)hipFree(t->d_rows);
   if (t->d_cmin) (void)hipFree(t->d_cmin);
+  if (t->d_strip_rows) (void)hipFree(t->d_strip_rows);
   for (auto& b : t->batch) {
     if (b.d_units) (void)hipFree(b.d_units);
     if (b.d_row_starts) (void)hipFree(b.d_row_starts);
@@ -228,6 +229,22 @@ int zk_sep_build(zk_plan* p, const double* basis) {
     bool nested = true;  // the strip kernel relies on limits that shrink towards the centre row (a disk's do)
     for (int r = 0; r + 1 < Q; ++r) nested = nested && cmin_full[r] >= cmin_full[r + 1];
     if (nested && (rc = upload(&t->d_cmin, cmin_full))) return rc;
+    if (nested && K % 2 == 0 && Q <= 32) {
+      // strip kernel, round-3 form (zk_sep_strip.hip): frame row fr is window row fr of the upper output and fr - 1 of the
+      // lower one; the sweep from the centre outwards first reaches the limit of the output that sees the frame row as its
+      // narrower window row (n1 column pairs), then runs on to the other's (n2 more)
+      std::vector<int32_t> rec(K + 1, 0);
+      for (int fr = 0; fr <= K; ++fr) {
+        const int c0 = fr < K ? cmin_full[fr] : Q, c1 = fr > 0 ? cmin_full[fr - 1] : Q;
+        const bool first_is_1 = fr < Q;
+        const int ca = first_is_1 ? c1 : c0, cb = first_is_1 ? c0 : c1;
+        if (ca < cb) return zk_fail(ZK_E_BADARG, "internal: strip limits are not nested");
+        if (cb >= Q) continue;
+        const int n1 = ca < Q ? Q - ca : 0;
+        rec[fr] = n1 | ((Q - cb - n1) << 8);
+      }
+      if ((rc = upload(&t->d_strip_rows, rec))) return rc;
+    }
   }
 
   // ---- batch kernel unit lists ------------------------------------------------------------------

@@ -45,15 +45,8 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip_kernel(
   const int k0 = blockIdx.x * 64;
   const int tile_elems = (K + 7) * tile_pitch;
 
-  for (int e = tid; e < tile_elems; e += 256) {
-    const int tr = e / tile_pitch;
-    const int tc = e - tr * tile_pitch;
-    const int ii = i0 - ea + tr;
-    const int kk = k0 - ea + tc;
-    double v = 0.0;
-    if (ii >= 0 && ii < H && kk >= 0 && kk < W) v = (double)img[(long long)ii * W + kk];
-    tile[e] = v;
-  }
+  zk_stage_tile(tile, img, H, W, i0 - ea, k0 - ea, K + 7, tile_pitch);
+  (void)tile_elems;
   __syncthreads();
 
   zk_sep_acc<NMAX> acc0, acc1;  // moments of output rows i0 + 2 wave and i0 + 2 wave + 1 (only M is used)
@@ -152,10 +145,242 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the same algorithm with the scalar bookkeeping removed (even K; odd K keeps the kernel above).
+// profiles/r02_sq_counters.txt had the kernel above at SALU : VALU = 0.40 and VALU-busy 0.63: per group of three column
+// pairs ~13 scalar ALU instructions (three 64-bit table pointers, counters, compares), six scalar loads, and one exposed
+// s_waitcnt for all of them; per frame row two table look-ups, selects and pointer products.  Here
+//   * a frame row is ONE record (host table, one s_load_dword): n1 = column pairs up to the narrower output's limit,
+//     n2 = the further pairs up to the wider one's;
+//   * the sweep runs centre-outwards over the stream kernel's full-width table (P_1 .. P_nmax of column Q + t, rows
+//     ascending with the sweep, P_0 = 1 implicit: one s_load_dwordx16 per column pair at n_max 8), so that the second
+//     sweep simply continues where the first stopped;
+//   * a sweep of n pairs is a jump into straight-line code (a switch whose cases fall through, aligned at the sweep's
+//     END): no counters, no compares, every table / LDS address an immediate off three bases set once per sweep;
+//   * the code is software-pipelined by hand: block j waits for ITS operands (requested by block j + 1), requests those
+//     of block j - 1 into the other register set (static: sets alternate with j), then does its 11 f64 operations.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef ZK_STRIP2
+#define ZK_STRIP2 1
+#endif
+
+// Operand requests the compiler cannot move: the pipeline below relies on a block's operands being REQUESTED one block
+// ahead.  Written as plain loads, LLVM sinks each request into the block that uses it (it is dead on the path that leaves
+// the sweep early) and the pipeline collapses into load - wait - use per column.  As volatile asm the requests stay where
+// they are written; the kernel waits for them itself (ZK_LGKM_WAIT: lgkmcnt(0)) before the first use.
+// The compiler takes an asm's outputs for written when the asm has issued, so nothing tells it that the hardware will write
+// those registers LATER: a register set whose request is dead on some path (the one past the end of a sweep) would be free
+// for reuse at once, and the landing data would then overwrite whatever the compiler put there (first seen as a memory
+// aperture fault: a pointer rebuilt in those SGPRs).  keep() -- an empty asm that reads the registers -- placed after the
+// wait that covers the request keeps them allocated until the data has landed.
+typedef double zk_v8d __attribute__((ext_vector_type(8)));
+typedef double zk_v4d __attribute__((ext_vector_type(4)));
+typedef double zk_v2d __attribute__((ext_vector_type(2)));
+template <int NMAX>
+struct zk_sgpr_row;  // P_1 .. P_NMAX of one table row in SGPRs
+template <>
+struct zk_sgpr_row<8> {
+  zk_v8d v;
+  template <int OFF>
+  __device__ __forceinline__ void request(const ZK_CONST double* p) {
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "n"(OFF));
+  }
+  __device__ __forceinline__ double operator[](int i) const { return v[i]; }
+  __device__ __forceinline__ void keep() const { asm volatile("" ::"s"(v)); }
+};
+template <>
+struct zk_sgpr_row<6> {
+  zk_v4d a;
+  zk_v2d b;
+  template <int OFF>
+  __device__ __forceinline__ void request(const ZK_CONST double* p) {
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(a) : "s"(p), "n"(OFF));
+    asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(b) : "s"(p), "n"(OFF + 32));
+  }
+  __device__ __forceinline__ double operator[](int i) const { return i < 4 ? a[i] : b[i - 4]; }
+  __device__ __forceinline__ void keep() const { asm volatile("" ::"s"(a), "s"(b)); }
+};
+template <>
+struct zk_sgpr_row<4> {
+  zk_v4d a;
+  template <int OFF>
+  __device__ __forceinline__ void request(const ZK_CONST double* p) {
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(a) : "s"(p), "n"(OFF));
+  }
+  __device__ __forceinline__ double operator[](int i) const { return a[i]; }
+  __device__ __forceinline__ void keep() const { asm volatile("" ::"s"(a)); }
+};
+template <int OFF>
+__device__ __forceinline__ double zk_lds_request(unsigned addr) {
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ unsigned zk_lds_addr(const double* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const double*)p;
+}
+
+template <int NMAX, typename T, int QM>
+__global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
+    const T* __restrict__ img, double* __restrict__ out, const int32_t* __restrict__ row_tab,
+    const double* __restrict__ pfull, const double* __restrict__ tmat, const int32_t* __restrict__ colmap, int K, int H,
+    int W, int row0, int n_rows, int tile_pitch, long long plane) {
+  using S = zk_sep_set<NMAX>;
+  constexpr int YROW = ZK_STREAM_ROW(NMAX);
+  extern __shared__ __attribute__((aligned(16))) double tile[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Q = K / 2;
+  const int ea = K - 1 - (K - 1) / 2;
+  const int i0 = row0 + blockIdx.y * 8;
+  const int k0 = blockIdx.x * 64;
+  const int tile_elems = (K + 7) * tile_pitch;
+
+  zk_stage_tile(tile, img, H, W, i0 - ea, k0 - ea, K + 7, tile_pitch);
+  (void)tile_elems;
+  __syncthreads();
+
+  zk_sep_acc<NMAX> acc0, acc1;  // moments of output rows i0 + 2 wave and i0 + 2 wave + 1 (only M is used)
+  acc0.clear_moments();
+  acc1.clear_moments();
+  const ZK_CONST int32_t* rtab = zk_const(row_tab);
+  const ZK_CONST double* py = zk_const(pfull);
+  const double* __restrict__ mine = tile + (2 * wave) * tile_pitch + lane;  // window row 0 of output 0
+
+  double X[S::NA];
+  // n column pairs of frame row `row` starting at sweep index t0 (t = 0: the two centre columns), outwards
+  auto sweep = [&](const double* __restrict__ row, int t0, int n) __attribute__((always_inline)) {
+    if (n == 0) return;
+    // block i (sweep index t0 + i) uses table row pB + i YROW and the pixels at LDS bytes La + 8 (QM-1-i) (left) and
+    // Ra + 8 i (right): every offset an immediate
+    const ZK_CONST double* pB = py + (Q + t0) * YROW;
+    const unsigned La = zk_lds_addr(row + (Q - 1 - t0) - (QM - 1));
+    const unsigned Ra = zk_lds_addr(row + (Q + t0));
+    zk_sgpr_row<NMAX> P0, P1 = {};
+    double a0, b0, a1 = 0.0, b1 = 0.0;
+    P0.template request<0>(pB);
+    a0 = zk_lds_request<(QM - 1) * 8>(La);
+    b0 = zk_lds_request<0>(Ra);
+    // block I: wait for ITS operands (requested one block earlier), request those of block I + 1 into the other register
+    // set (one column past the sweep at its end: the table and the tile row have the room), then the arithmetic
+#define ZK_STRIP_BLOCK(I)                                                                       \
+  {                                                                                             \
+    ZK_LGKM_WAIT();                                                                             \
+    double s_, d_;                                                                              \
+    if constexpr (((I)&1) != 0) {                                                               \
+      s_ = b1 + a1;                                                                             \
+      d_ = b1 - a1;                                                                             \
+      if constexpr ((I) + 1 < QM) {                                                             \
+        P0.template request<((I) + 1) * YROW * 8>(pB);                                          \
+        a0 = zk_lds_request<(QM - 2 - (I) >= 0 ? QM - 2 - (I) : 0) * 8>(La);                    \
+        b0 = zk_lds_request<((I) + 1) * 8>(Ra);                                                 \
+      }                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+      X[0] += s_;                                                                               \
+      _Pragma("unroll") for (int i = 1; i < S::NA; ++i) X[i] = __builtin_fma((i & 1) ? d_ : s_, P1[i - 1], X[i]); \
+    } else {                                                                                    \
+      s_ = b0 + a0;                                                                             \
+      d_ = b0 - a0;                                                                             \
+      if constexpr ((I) + 1 < QM) {                                                             \
+        P1.template request<((I) + 1) * YROW * 8>(pB);                                          \
+        a1 = zk_lds_request<(QM - 2 - (I) >= 0 ? QM - 2 - (I) : 0) * 8>(La);                    \
+        b1 = zk_lds_request<((I) + 1) * 8>(Ra);                                                 \
+      }                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+      X[0] += s_;                                                                               \
+      _Pragma("unroll") for (int i = 1; i < S::NA; ++i) X[i] = __builtin_fma((i & 1) ? d_ : s_, P0[i - 1], X[i]); \
+    }                                                                                           \
+  }
+#define ZK_STRIP_STEP(I) \
+  ZK_STRIP_BLOCK(I)      \
+  if (n <= (I) + 1) break;
+    do {
+      ZK_STRIP_STEP(0) ZK_STRIP_STEP(1) ZK_STRIP_STEP(2) ZK_STRIP_STEP(3) ZK_STRIP_STEP(4) ZK_STRIP_STEP(5)
+      ZK_STRIP_STEP(6) ZK_STRIP_STEP(7) ZK_STRIP_STEP(8) ZK_STRIP_STEP(9) ZK_STRIP_STEP(10) ZK_STRIP_STEP(11)
+      ZK_STRIP_STEP(12) ZK_STRIP_STEP(13) ZK_STRIP_STEP(14)
+      if constexpr (QM > 16) {
+        ZK_STRIP_STEP(15) ZK_STRIP_STEP(16) ZK_STRIP_STEP(17) ZK_STRIP_STEP(18) ZK_STRIP_STEP(19) ZK_STRIP_STEP(20)
+        ZK_STRIP_STEP(21) ZK_STRIP_STEP(22) ZK_STRIP_STEP(23) ZK_STRIP_STEP(24) ZK_STRIP_STEP(25) ZK_STRIP_STEP(26)
+        ZK_STRIP_STEP(27) ZK_STRIP_STEP(28) ZK_STRIP_STEP(29) ZK_STRIP_STEP(30)
+      }
+      ZK_STRIP_BLOCK(QM - 1)
+    } while (0);
+    ZK_LGKM_WAIT();  // the request past the sweep has landed ...
+    P0.keep();       // ... and until here nothing else may live in the registers it was written to
+    P1.keep();
+    asm volatile("" ::"v"(a0), "v"(b0), "v"(a1), "v"(b1));
+#undef ZK_STRIP_STEP
+#undef ZK_STRIP_BLOCK
+  };
+
+  // frame row fr (relative to output 0's window) is window row fr of output 0 and fr - 1 of output 1; in the upper half
+  // of the window output 1 has the narrower row and is served first, in the lower half output 0 (see the kernel above)
+  auto frame_row = [&](int fr, auto first_is_1) __attribute__((always_inline)) {
+    constexpr bool F1 = decltype(first_is_1)::value;
+    const int rec = rtab[fr];
+    if (rec == 0) return;  // no disk pixel of either output in this frame row
+    const int n1 = rec & 0xff, n2 = rec >> 8;
+#pragma unroll
+    for (int i = 0; i < S::NA; ++i) X[i] = 0.0;
+    const double* __restrict__ row = mine + fr * tile_pitch;
+    sweep(row, 0, n1);
+    // (unconditional: with n1 = 0 -- the first output has no disk pixel in this frame row -- X is still zero and the
+    //  moments do not change; a branch here would make the compiler keep two versions of 45 accumulators)
+    if constexpr (F1) acc1.stream_accumulate(X, py + (n1 ? fr - 1 : fr) * YROW);
+    else acc0.stream_accumulate(X, py + fr * YROW);
+    sweep(row, n1, n2);
+    if constexpr (F1) acc0.stream_accumulate(X, py + fr * YROW);
+    else acc1.stream_accumulate(X, py + (fr - 1) * YROW);
+  };
+  for (int fr = 0; fr < Q; ++fr) frame_row(fr, std::true_type{});
+  for (int fr = Q; fr <= K; ++fr) frame_row(fr, std::false_type{});
+
+  // Z = T M of both outputs together (every T entry fetched once), both stores of a plane off one base
+  const int ok = k0 + lane;
+  const int oi = i0 + 2 * wave;
+  if (ok >= W || oi >= row0 + n_rows) return;
+  const bool two = oi + 1 < row0 + n_rows;  // wave-uniform
+  const ZK_CONST int32_t* cmap = zk_const(colmap);
+  double* __restrict__ dst = out + (long long)(oi - row0) * W + ok;
+  zk_sep_transform2<NMAX>(acc0, acc1, zk_const(tmat), [&](auto slot, double z0, double z1) {
+    const int col = cmap[slot];
+    if (col >= 0) {
+      double* __restrict__ d = dst + col * plane;
+      d[0] = z0;
+      if (two) d[W] = z1;
+    }
+  });
+}
+
+template <int NMAX, typename T, int QM>
+int launch_strip2(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out, hipStream_t s) {
+  const zk_sep_tables* t = p->sep;
+  const size_t lds = (size_t)(p->size + 7) * t->tile_pitch * sizeof(double);
+  auto kern = zk_frame_strip2_kernel<NMAX, T, QM>;
+  if (lds > 64 * 1024)
+    ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long long plane = zk_out_plane(p, n_rows, W);
+  return zk_for_row_bands(row0, n_rows, W, 8, [&](int64_t r0, int64_t nr, long long off) {
+    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((nr + 7) / 8));
+    int rc = zk_prof_begin(p, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out + off, t->d_strip_rows, t->d_pfull, t->d_T, t->d_colmap,
+                       p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane);
+    ZK_HIP(hipGetLastError());
+    return zk_prof_end(p, s);
+  });
+}
+
 template <int NMAX, typename T>
 int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out,
                hipStream_t s) {
   const zk_sep_tables* t = p->sep;
+  static const bool v1 = getenv("ZK_STRIP_V1") != nullptr;  // A/B runs: the round-2 kernel
+  if (ZK_STRIP2 && !v1 && t->d_strip_rows && p->size % 2 == 0) {
+    if (p->size <= 32) return launch_strip2<NMAX, T, 16>(p, in, H, W, row0, n_rows, out, s);
+    return launch_strip2<NMAX, T, 32>(p, in, H, W, row0, n_rows, out, s);
+  }
   const size_t lds = (size_t)(p->size + 7) * t->tile_pitch * sizeof(double);
   auto kern = zk_frame_strip_kernel<NMAX, T>;
   if (lds > 64 * 1024)
