@@ -141,6 +141,7 @@ struct zk_sep_unit {    // batch kernel: 16 (float32) / 8 (float64) quadrant col
 };
 
 #define ZK_STREAM_ROW(NMAX) (((NMAX) + 1) & ~1)  // doubles per row of the stream kernel's table (P_1 .. P_NMAX)
+#define ZK_SPLIT_HALF 6  // strip kernel, n_max 10 / 12: doubles per half of a row of the parity-split x table (d_psplit)
 #define ZK_STREAM_PAD 4  // zero rows either side of the stream kernel's Legendre table (one granule of pixels)
 
 // Stream ("flat") batch kernel, zk_sep_stream.hip: a patch is read as the contiguous pixel stream it is
@@ -169,6 +170,8 @@ struct zk_sep_tables {
   int n_rows = 0;
   zk_sep_row* d_rows = nullptr;    // [n_rows]
   int32_t* d_cmin = nullptr;       // [K] first quadrant column inside the disk of window row r (Q: none); strip kernel
+  double* d_psplit_alloc = nullptr; // strip kernel, n_max 9-12: ZK_STREAM_PAD zero rows | [K][2 ZK_SPLIT_HALF] | pad: per column
+  double* d_psplit = nullptr;       // [P_2 P_4 .. P_12 | P_1 P_3 .. P_11] (zero beyond the kernel's n_max)
   int32_t* d_strip_rows = nullptr; // [K + 1] strip kernel (even K): per frame row n1 | n2 << 8, the column pairs of its two sweeps
   int tile_pitch = 0;
   // fused maps: fold weights + [n_theta][2][kernel_nmax] cos / sin(m theta).  One device table per distinct
@@ -366,8 +369,10 @@ struct zk_sep_acc : zk_sep_rows<NMAX, MASK> {
   template <int s, typename PY>
   __device__ __forceinline__ void stream_slot(const double (&X)[S::NA], const PY& py) {
     constexpr int a = S::slot_a(s), b = S::slot_b(s);  // (constexpr: otherwise evaluated at run time for large NMAX)
-    if constexpr (b == 0) M[s] += X[a];
-    else M[s] = __builtin_fma(py[b - 1], X[a], M[s]);
+    if constexpr (((MASK >> S::cls_of(a, b)) & 1) != 0) {
+      if constexpr (b == 0) M[s] += X[a];
+      else M[s] = __builtin_fma(py[b - 1], X[a], M[s]);
+    }
   }
   template <typename PY, int... Is>
   __device__ __forceinline__ void stream_all(const double (&X)[S::NA], const PY& py, std::integer_sequence<int, Is...>) {
@@ -431,8 +436,8 @@ struct zk_sep_acc : zk_sep_rows<NMAX, MASK> {
 
 // Z = T M for TWO accumulator sets at once (strip dense kernel: a lane's two outputs go to the same planes, one row
 // apart): every entry of T is fetched once and feeds two FMAs.  emit(slot, z_a, z_b).
-template <int NMAX, int CLS, int J, typename F>
-__device__ __forceinline__ void zk_sep_transform2_row(const zk_sep_acc<NMAX>& A, const zk_sep_acc<NMAX>& B,
+template <int NMAX, int MASK, int CLS, int J, typename F>
+__device__ __forceinline__ void zk_sep_transform2_row(const zk_sep_acc<NMAX, MASK>& A, const zk_sep_acc<NMAX, MASK>& B,
                                                       const ZK_CONST double* tmat, F&& emit) {
   using S = zk_sep_set<NMAX>;
   using P = zk_sep_meta<NMAX>;
@@ -451,19 +456,19 @@ __device__ __forceinline__ void zk_sep_transform2_row(const zk_sep_acc<NMAX>& A,
   emit(std::integral_constant<int, off + J>{}, za, zb);
   __builtin_amdgcn_sched_barrier(0);  // (as transform_row: keep the rows' scalar loads from piling up at the top)
 }
-template <int NMAX, int CLS, typename F, int... Js>
-__device__ __forceinline__ void zk_sep_transform2_rows(const zk_sep_acc<NMAX>& A, const zk_sep_acc<NMAX>& B,
+template <int NMAX, int MASK, int CLS, typename F, int... Js>
+__device__ __forceinline__ void zk_sep_transform2_rows(const zk_sep_acc<NMAX, MASK>& A, const zk_sep_acc<NMAX, MASK>& B,
                                                        const ZK_CONST double* tmat, F&& emit, std::integer_sequence<int, Js...>) {
-  (zk_sep_transform2_row<NMAX, CLS, Js>(A, B, tmat, emit), ...);
+  (zk_sep_transform2_row<NMAX, MASK, CLS, Js>(A, B, tmat, emit), ...);
 }
-template <int NMAX, typename F>
-__device__ __forceinline__ void zk_sep_transform2(const zk_sep_acc<NMAX>& A, const zk_sep_acc<NMAX>& B, const ZK_CONST double* tmat,
-                                                  F&& emit) {
+template <int NMAX, int MASK, typename F>
+__device__ __forceinline__ void zk_sep_transform2(const zk_sep_acc<NMAX, MASK>& A, const zk_sep_acc<NMAX, MASK>& B,
+                                                  const ZK_CONST double* tmat, F&& emit) {
   using S = zk_sep_set<NMAX>;
-  zk_sep_transform2_rows<NMAX, ZK_EE>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_EE)>{});
-  zk_sep_transform2_rows<NMAX, ZK_OE>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_OE)>{});
-  zk_sep_transform2_rows<NMAX, ZK_EO>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_EO)>{});
-  zk_sep_transform2_rows<NMAX, ZK_OO>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_OO)>{});
+  if constexpr ((MASK >> ZK_EE) & 1) zk_sep_transform2_rows<NMAX, MASK, ZK_EE>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_EE)>{});
+  if constexpr ((MASK >> ZK_OE) & 1) zk_sep_transform2_rows<NMAX, MASK, ZK_OE>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_OE)>{});
+  if constexpr ((MASK >> ZK_EO) & 1) zk_sep_transform2_rows<NMAX, MASK, ZK_EO>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_EO)>{});
+  if constexpr ((MASK >> ZK_OO) & 1) zk_sep_transform2_rows<NMAX, MASK, ZK_OO>(A, B, tmat, emit, std::make_integer_sequence<int, S::cls_count(ZK_OO)>{});
 }
 
 template <typename F, int... Is>

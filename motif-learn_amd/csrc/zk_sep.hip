@@ -69,6 +69,7 @@ void zk_sep_free(zk_plan* p) {
   if (t->d_rows) (void)hipFree(t->d_rows);
   if (t->d_cmin) (void)hipFree(t->d_cmin);
   if (t->d_strip_rows) (void)hipFree(t->d_strip_rows);
+  if (t->d_psplit_alloc) (void)hipFree(t->d_psplit_alloc);
   for (auto& b : t->batch) {
     if (b.d_units) (void)hipFree(b.d_units);
     if (b.d_row_starts) (void)hipFree(b.d_row_starts);
@@ -327,6 +328,17 @@ int zk_sep_build(zk_plan* p, const double* basis) {
       for (int a = 1; a < D; ++a) pfull[(size_t)(c + ZK_STREAM_PAD) * srow + a - 1] = (double)P[(size_t)c * D + a];
     if ((rc = upload(&t->d_pfull_alloc, pfull))) return rc;
     t->d_pfull = t->d_pfull_alloc + ZK_STREAM_PAD * srow;
+    if (knm > 8 && knm <= 2 * ZK_SPLIT_HALF) {
+      // the same values split by the parity of the degree: the x-even / x-odd passes of the strip kernel (zk_sep_strip.hip)
+      // each request one half of a row
+      const int prow = 2 * ZK_SPLIT_HALF;
+      std::vector<double> ps((size_t)(K + 2 * ZK_STREAM_PAD) * prow, 0.0);
+      for (int c = 0; c < K; ++c)
+        for (int a = 1; a < D; ++a)
+          ps[(size_t)(c + ZK_STREAM_PAD) * prow + ((a & 1) ? ZK_SPLIT_HALF + (a - 1) / 2 : a / 2 - 1)] = (double)P[(size_t)c * D + a];
+      if ((rc = upload(&t->d_psplit_alloc, ps))) return rc;
+      t->d_psplit = t->d_psplit_alloc + ZK_STREAM_PAD * prow;
+    }
     std::vector<zk_stream_row> srows;
     for (int r = 0; r < K; ++r) {
       int lo = -1, hi = -1;

@@ -167,129 +167,142 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip_kernel(
 // Operand requests the compiler cannot move: the pipeline below relies on a block's operands being REQUESTED one block
 // ahead.  Written as plain loads, LLVM sinks each request into the block that uses it (it is dead on the path that leaves
 // the sweep early) and the pipeline collapses into load - wait - use per column.  As volatile asm the requests stay where
-// they are written; the kernel waits for them itself (ZK_LGKM_WAIT: lgkmcnt(0)) before the first use.
-// The compiler takes an asm's outputs for written when the asm has issued, so nothing tells it that the hardware will write
-// those registers LATER: a register set whose request is dead on some path (the one past the end of a sweep) would be free
-// for reuse at once, and the landing data would then overwrite whatever the compiler put there (first seen as a memory
-// aperture fault: a pointer rebuilt in those SGPRs).  keep() -- an empty asm that reads the registers -- placed after the
-// wait that covers the request keeps them allocated until the data has landed.
+// they are written, and the kernel waits for them itself before the first use.
+// The compiler takes an asm's outputs for written when the asm has issued; nothing tells it that the hardware writes them
+// LATER.  Two things went wrong before the present form (the second one as a memory-aperture fault on the GPU):
+//   * arithmetic on the requested values has no dependence on a bare s_waitcnt and was placed ABOVE it;
+//   * a register set whose request is dead on some path (the one past the end of a sweep) was reused at once -- for a
+//     re-load of kernel arguments -- and the late table row then overwrote the pointers.
+// So the wait is an asm that takes the requested registers as read-write operands: every use depends on it, and the
+// registers stay allocated from the request to the wait.  Requests take the CURRENT block's pixel operands the same way,
+// which keeps the block's arithmetic behind them (they must issue early to be of use).  tools/check_async_requests.py
+// re-checks the generated code (tests/test_isa_checks.py).
 typedef double zk_v8d __attribute__((ext_vector_type(8)));
 typedef double zk_v4d __attribute__((ext_vector_type(4)));
 typedef double zk_v2d __attribute__((ext_vector_type(2)));
-template <int NMAX>
-struct zk_sgpr_row;  // P_1 .. P_NMAX of one table row in SGPRs
+template <int N>
+struct zk_sgpr_row;  // N doubles of one table row in SGPRs
 template <>
 struct zk_sgpr_row<8> {
   zk_v8d v;
   template <int OFF>
-  __device__ __forceinline__ void request(const ZK_CONST double* p) {
-    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "n"(OFF));
+  __device__ __forceinline__ void request(const ZK_CONST double* p, double& after) {
+    asm volatile("s_load_dwordx16 %0, %2, %3" : "=s"(v), "+v"(after) : "s"(p), "n"(OFF));
   }
+  __device__ __forceinline__ void wait(double& a, double& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+v"(a), "+v"(b)); }
   __device__ __forceinline__ double operator[](int i) const { return v[i]; }
-  __device__ __forceinline__ void keep() const { asm volatile("" ::"s"(v)); }
 };
 template <>
 struct zk_sgpr_row<6> {
   zk_v4d a;
   zk_v2d b;
   template <int OFF>
-  __device__ __forceinline__ void request(const ZK_CONST double* p) {
-    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(a) : "s"(p), "n"(OFF));
+  __device__ __forceinline__ void request(const ZK_CONST double* p, double& after) {
+    asm volatile("s_load_dwordx8 %0, %2, %3" : "=s"(a), "+v"(after) : "s"(p), "n"(OFF));
     asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(b) : "s"(p), "n"(OFF + 32));
   }
+  __device__ __forceinline__ void wait(double& x, double& y) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+v"(x), "+v"(y));
+  }
   __device__ __forceinline__ double operator[](int i) const { return i < 4 ? a[i] : b[i - 4]; }
-  __device__ __forceinline__ void keep() const { asm volatile("" ::"s"(a), "s"(b)); }
 };
 template <>
 struct zk_sgpr_row<4> {
   zk_v4d a;
   template <int OFF>
-  __device__ __forceinline__ void request(const ZK_CONST double* p) {
-    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(a) : "s"(p), "n"(OFF));
+  __device__ __forceinline__ void request(const ZK_CONST double* p, double& after) {
+    asm volatile("s_load_dwordx8 %0, %2, %3" : "=s"(a), "+v"(after) : "s"(p), "n"(OFF));
   }
+  __device__ __forceinline__ void wait(double& x, double& y) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(x), "+v"(y)); }
   __device__ __forceinline__ double operator[](int i) const { return a[i]; }
-  __device__ __forceinline__ void keep() const { asm volatile("" ::"s"(a)); }
 };
 template <int OFF>
-__device__ __forceinline__ double zk_lds_request(unsigned addr) {
+__device__ __forceinline__ double zk_lds_request(unsigned addr, double& after) {
   double v;
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64 %0, %2 offset:%3" : "=v"(v), "+v"(after) : "v"(addr), "n"(OFF));
   return v;
 }
 __device__ __forceinline__ unsigned zk_lds_addr(const double* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const double*)p;
 }
 
-template <int NMAX, typename T, int QM>
-__global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
-    const T* __restrict__ img, double* __restrict__ out, const int32_t* __restrict__ row_tab,
-    const double* __restrict__ pfull, const double* __restrict__ tmat, const int32_t* __restrict__ colmap, int K, int H,
-    int W, int row0, int n_rows, int tile_pitch, long long plane) {
+// One pass over the staged tile for the parity classes of MASK: all four (n_max <= 8), or the two classes of one x parity
+// (n_max 10 / 12, where two full accumulator sets do not fit a lane's registers -- 2 x 91 doubles at n_max 12 -- but two
+// half sets do: the kernel then runs the x-even classes EE | EO and the x-odd classes OE | OO one after the other on the same
+// tile; a sweep of the x-even pass needs only the sums f(q) + f(K-1-q) and the even-degree table entries, the x-odd pass the
+// differences and the odd degrees, so the two passes together do the column work of ONE full pass).
+//   XT: table of the sweep, XROW doubles per column; XN entries used: entry e is the factor of degree XDEG(e)
+template <int NMAX, int QM, int MASK>
+struct zk_strip_cfg {
   using S = zk_sep_set<NMAX>;
+  static constexpr bool kAll = MASK == 15;
+  static constexpr bool kEven = (MASK & ((1 << ZK_EE) | (1 << ZK_EO))) != 0, kOdd = (MASK & ((1 << ZK_OE) | (1 << ZK_OO))) != 0;
+  // full table: P_1 .. P_NMAX (ZK_STREAM_ROW doubles); split table (zk_sep.hip, d_psplit): [P_2 P_4 ..|pad][P_1 P_3 ..|pad]
+  static constexpr int XROW = kAll ? ZK_STREAM_ROW(NMAX) : 2 * ZK_SPLIT_HALF;
+  static constexpr int XN = kAll ? NMAX : ZK_SPLIT_HALF;           // doubles requested per column
+  static constexpr int XOFF = (!kAll && kOdd) ? ZK_SPLIT_HALF : 0;  // first double of this pass inside a table row
+  // table entry of degree a (a >= 1) inside the requested run
+  static constexpr int entry(int a) { return kAll ? a - 1 : (a & 1) ? (a - 1) / 2 : a / 2 - 1; }
+  static constexpr bool has(int a) { return (a & 1) ? kOdd : kEven; }
+};
+
+template <int NMAX, int QM, int MASK>
+__device__ __forceinline__ void zk_strip_pass(const double* __restrict__ tile, const ZK_CONST int32_t* rtab,
+                                              const ZK_CONST double* px, const ZK_CONST double* py, const ZK_CONST double* tb,
+                                              const ZK_CONST int32_t* cmap, double* __restrict__ dst, bool store, bool two, int K,
+                                              int W, int tile_pitch, long long plane, int wave, int lane) {
+  using S = zk_sep_set<NMAX>;
+  using C = zk_strip_cfg<NMAX, QM, MASK>;
   constexpr int YROW = ZK_STREAM_ROW(NMAX);
-  extern __shared__ __attribute__((aligned(16))) double tile[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int XROW = C::XROW;
   const int Q = K / 2;
-  const int ea = K - 1 - (K - 1) / 2;
-  const int i0 = row0 + blockIdx.y * 8;
-  const int k0 = blockIdx.x * 64;
-  const int tile_elems = (K + 7) * tile_pitch;
-
-  zk_stage_tile(tile, img, H, W, i0 - ea, k0 - ea, K + 7, tile_pitch);
-  (void)tile_elems;
-  __syncthreads();
-
-  zk_sep_acc<NMAX> acc0, acc1;  // moments of output rows i0 + 2 wave and i0 + 2 wave + 1 (only M is used)
+  zk_sep_acc<NMAX, MASK> acc0, acc1;  // moments of output rows i0 + 2 wave and i0 + 2 wave + 1 (only M is used)
   acc0.clear_moments();
   acc1.clear_moments();
-  const ZK_CONST int32_t* rtab = zk_const(row_tab);
-  const ZK_CONST double* py = zk_const(pfull);
   const double* __restrict__ mine = tile + (2 * wave) * tile_pitch + lane;  // window row 0 of output 0
 
   double X[S::NA];
   // n column pairs of frame row `row` starting at sweep index t0 (t = 0: the two centre columns), outwards
   auto sweep = [&](const double* __restrict__ row, int t0, int n) __attribute__((always_inline)) {
     if (n == 0) return;
-    // block i (sweep index t0 + i) uses table row pB + i YROW and the pixels at LDS bytes La + 8 (QM-1-i) (left) and
+    // block i (sweep index t0 + i) uses table row pB + i XROW and the pixels at LDS bytes La + 8 (QM-1-i) (left) and
     // Ra + 8 i (right): every offset an immediate
-    const ZK_CONST double* pB = py + (Q + t0) * YROW;
+    const ZK_CONST double* pB = px + (Q + t0) * XROW + C::XOFF;
     const unsigned La = zk_lds_addr(row + (Q - 1 - t0) - (QM - 1));
     const unsigned Ra = zk_lds_addr(row + (Q + t0));
-    zk_sgpr_row<NMAX> P0, P1 = {};
+    zk_sgpr_row<C::XN> P0, P1 = {};
     double a0, b0, a1 = 0.0, b1 = 0.0;
-    P0.template request<0>(pB);
-    a0 = zk_lds_request<(QM - 1) * 8>(La);
-    b0 = zk_lds_request<0>(Ra);
+    P0.template request<0>(pB, a1);
+    a0 = zk_lds_request<(QM - 1) * 8>(La, a1);
+    b0 = zk_lds_request<0>(Ra, b1);
+    auto arith = [&](double a, double b, const zk_sgpr_row<C::XN>& P) __attribute__((always_inline)) {
+      [[maybe_unused]] const double s_ = b + a;
+      [[maybe_unused]] const double d_ = b - a;
+      if constexpr (C::kEven) X[0] += s_;
+#pragma unroll
+      for (int i = 1; i < S::NA; ++i)
+        if (C::has(i)) X[i] = __builtin_fma((i & 1) ? d_ : s_, P[C::entry(i)], X[i]);
+    };
     // block I: wait for ITS operands (requested one block earlier), request those of block I + 1 into the other register
     // set (one column past the sweep at its end: the table and the tile row have the room), then the arithmetic
 #define ZK_STRIP_BLOCK(I)                                                                       \
   {                                                                                             \
-    ZK_LGKM_WAIT();                                                                             \
-    double s_, d_;                                                                              \
     if constexpr (((I)&1) != 0) {                                                               \
-      s_ = b1 + a1;                                                                             \
-      d_ = b1 - a1;                                                                             \
+      P1.wait(a1, b1);                                                                          \
       if constexpr ((I) + 1 < QM) {                                                             \
-        P0.template request<((I) + 1) * YROW * 8>(pB);                                          \
-        a0 = zk_lds_request<(QM - 2 - (I) >= 0 ? QM - 2 - (I) : 0) * 8>(La);                    \
-        b0 = zk_lds_request<((I) + 1) * 8>(Ra);                                                 \
+        P0.template request<((I) + 1) * XROW * 8>(pB, a1);                                      \
+        a0 = zk_lds_request<(QM - 2 - (I) >= 0 ? QM - 2 - (I) : 0) * 8>(La, a1);                \
+        b0 = zk_lds_request<((I) + 1) * 8>(Ra, b1);                                             \
       }                                                                                         \
-      __builtin_amdgcn_sched_barrier(0);                                                        \
-      X[0] += s_;                                                                               \
-      _Pragma("unroll") for (int i = 1; i < S::NA; ++i) X[i] = __builtin_fma((i & 1) ? d_ : s_, P1[i - 1], X[i]); \
+      arith(a1, b1, P1);                                                                        \
     } else {                                                                                    \
-      s_ = b0 + a0;                                                                             \
-      d_ = b0 - a0;                                                                             \
+      P0.wait(a0, b0);                                                                          \
       if constexpr ((I) + 1 < QM) {                                                             \
-        P1.template request<((I) + 1) * YROW * 8>(pB);                                          \
-        a1 = zk_lds_request<(QM - 2 - (I) >= 0 ? QM - 2 - (I) : 0) * 8>(La);                    \
-        b1 = zk_lds_request<((I) + 1) * 8>(Ra);                                                 \
+        P1.template request<((I) + 1) * XROW * 8>(pB, a0);                                      \
+        a1 = zk_lds_request<(QM - 2 - (I) >= 0 ? QM - 2 - (I) : 0) * 8>(La, a0);                \
+        b1 = zk_lds_request<((I) + 1) * 8>(Ra, b0);                                             \
       }                                                                                         \
-      __builtin_amdgcn_sched_barrier(0);                                                        \
-      X[0] += s_;                                                                               \
-      _Pragma("unroll") for (int i = 1; i < S::NA; ++i) X[i] = __builtin_fma((i & 1) ? d_ : s_, P0[i - 1], X[i]); \
+      arith(a0, b0, P0);                                                                        \
     }                                                                                           \
   }
 #define ZK_STRIP_STEP(I) \
@@ -306,10 +319,9 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
       }
       ZK_STRIP_BLOCK(QM - 1)
     } while (0);
-    ZK_LGKM_WAIT();  // the request past the sweep has landed ...
-    P0.keep();       // ... and until here nothing else may live in the registers it was written to
-    P1.keep();
-    asm volatile("" ::"v"(a0), "v"(b0), "v"(a1), "v"(b1));
+    // the request past the sweep has landed before anything else may live in the registers it was written to
+    P0.wait(a0, b0);
+    P1.wait(a1, b1);
 #undef ZK_STRIP_STEP
 #undef ZK_STRIP_BLOCK
   };
@@ -337,13 +349,8 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
   for (int fr = Q; fr <= K; ++fr) frame_row(fr, std::false_type{});
 
   // Z = T M of both outputs together (every T entry fetched once), both stores of a plane off one base
-  const int ok = k0 + lane;
-  const int oi = i0 + 2 * wave;
-  if (ok >= W || oi >= row0 + n_rows) return;
-  const bool two = oi + 1 < row0 + n_rows;  // wave-uniform
-  const ZK_CONST int32_t* cmap = zk_const(colmap);
-  double* __restrict__ dst = out + (long long)(oi - row0) * W + ok;
-  zk_sep_transform2<NMAX>(acc0, acc1, zk_const(tmat), [&](auto slot, double z0, double z1) {
+  if (!store) return;
+  zk_sep_transform2<NMAX, MASK>(acc0, acc1, tb, [&](auto slot, double z0, double z1) {
     const int col = cmap[slot];
     if (col >= 0) {
       double* __restrict__ d = dst + col * plane;
@@ -351,6 +358,38 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
       if (two) d[W] = z1;
     }
   });
+}
+
+template <int NMAX, typename T, int QM>
+__global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
+    const T* __restrict__ img, double* __restrict__ out, const int32_t* __restrict__ row_tab,
+    const double* __restrict__ xtab, const double* __restrict__ pfull, const double* __restrict__ tmat,
+    const int32_t* __restrict__ colmap, int K, int H, int W, int row0, int n_rows, int tile_pitch, long long plane) {
+  extern __shared__ __attribute__((aligned(16))) double tile[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ea = K - 1 - (K - 1) / 2;
+  const int i0 = row0 + blockIdx.y * 8;
+  const int k0 = blockIdx.x * 64;
+
+  zk_stage_tile(tile, img, H, W, i0 - ea, k0 - ea, K + 7, tile_pitch);
+  __syncthreads();
+
+  const int ok = k0 + lane;
+  const int oi = i0 + 2 * wave;
+  const bool store = ok < W && oi < row0 + n_rows;
+  const bool two = oi + 1 < row0 + n_rows;  // wave-uniform
+  double* __restrict__ dst = out + (long long)(oi - row0) * W + ok;
+  if constexpr (NMAX <= 8) {
+    zk_strip_pass<NMAX, QM, 15>(tile, zk_const(row_tab), zk_const(xtab), zk_const(pfull), zk_const(tmat), zk_const(colmap), dst, store,
+                                two, K, W, tile_pitch, plane, wave, lane);
+  } else {
+    zk_strip_pass<NMAX, QM, (1 << ZK_EE) | (1 << ZK_EO)>(tile, zk_const(row_tab), zk_const(xtab), zk_const(pfull), zk_const(tmat),
+                                                         zk_const(colmap), dst, store, two, K, W, tile_pitch, plane, wave, lane);
+    zk_strip_pass<NMAX, QM, (1 << ZK_OE) | (1 << ZK_OO)>(tile, zk_const(row_tab), zk_const(xtab), zk_const(pfull), zk_const(tmat),
+                                                         zk_const(colmap), dst, store, two, K, W, tile_pitch, plane, wave, lane);
+  }
 }
 
 template <int NMAX, typename T, int QM>
@@ -365,8 +404,8 @@ int launch_strip2(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0
     dim3 grid((unsigned)((W + 63) / 64), (unsigned)((nr + 7) / 8));
     int rc = zk_prof_begin(p, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out + off, t->d_strip_rows, t->d_pfull, t->d_T, t->d_colmap,
-                       p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out + off, t->d_strip_rows, NMAX <= 8 ? t->d_pfull : t->d_psplit,
+                       t->d_pfull, t->d_T, t->d_colmap, p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane);
     ZK_HIP(hipGetLastError());
     return zk_prof_end(p, s);
   });
@@ -381,20 +420,24 @@ int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, i
     if (p->size <= 32) return launch_strip2<NMAX, T, 16>(p, in, H, W, row0, n_rows, out, s);
     return launch_strip2<NMAX, T, 32>(p, in, H, W, row0, n_rows, out, s);
   }
-  const size_t lds = (size_t)(p->size + 7) * t->tile_pitch * sizeof(double);
-  auto kern = zk_frame_strip_kernel<NMAX, T>;
-  if (lds > 64 * 1024)
-    ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const long long plane = zk_out_plane(p, n_rows, W);
-  return zk_for_row_bands(row0, n_rows, W, 8, [&](int64_t r0, int64_t nr, long long off) {
-    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((nr + 7) / 8));
-    int rc = zk_prof_begin(p, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out + off, t->d_cmin, t->d_xq, t->d_pfull, t->d_T,
-                       t->d_colmap, p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane);
-    ZK_HIP(hipGetLastError());
-    return zk_prof_end(p, s);
-  });
+  if constexpr (NMAX > 8) {
+    return zk_fail(ZK_E_BADARG, "internal: the two-pass strip kernel needs its tables");
+  } else {
+    const size_t lds = (size_t)(p->size + 7) * t->tile_pitch * sizeof(double);
+    auto kern = zk_frame_strip_kernel<NMAX, T>;
+    if (lds > 64 * 1024)
+      ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long plane = zk_out_plane(p, n_rows, W);
+    return zk_for_row_bands(row0, n_rows, W, 8, [&](int64_t r0, int64_t nr, long long off) {
+      dim3 grid((unsigned)((W + 63) / 64), (unsigned)((nr + 7) / 8));
+      int rc = zk_prof_begin(p, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out + off, t->d_cmin, t->d_xq, t->d_pfull, t->d_T,
+                         t->d_colmap, p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane);
+      ZK_HIP(hipGetLastError());
+      return zk_prof_end(p, s);
+    });
+  }
 }
 
 template <typename T>
@@ -404,6 +447,8 @@ int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int
     case 4: return launch_one<4, T>(p, in, H, W, row0, n_rows, out, s);
     case 6: return launch_one<6, T>(p, in, H, W, row0, n_rows, out, s);
     case 8: return launch_one<8, T>(p, in, H, W, row0, n_rows, out, s);
+    case 10: return launch_one<10, T>(p, in, H, W, row0, n_rows, out, s);
+    case 12: return launch_one<12, T>(p, in, H, W, row0, n_rows, out, s);
   }
   return zk_fail(ZK_E_BADARG, "no strip frame kernel for this n_max");
 }
@@ -412,7 +457,10 @@ int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int
 
 bool zk_sep_strip_available(const zk_plan* p, int dtype) {
   (void)dtype;
-  if (!zk_sep_frame_available(p, dtype) || p->sep->kernel_nmax > 8 || !p->sep->d_pfull || !p->sep->d_cmin) return false;
+  if (!zk_sep_frame_available(p, dtype) || p->sep->kernel_nmax > 12 || !p->sep->d_pfull || !p->sep->d_cmin) return false;
+  // n_max 9 - 12: only the two-pass form exists (even window sizes, zk_sep.hip builds its tables)
+  static const bool no12 = getenv("ZK_STRIP_NO_SPLIT") != nullptr;  // A/B runs: the one-output kernel
+  if (p->sep->kernel_nmax > 8 && (no12 || !p->sep->d_psplit || !p->sep->d_strip_rows || p->size % 2 != 0)) return false;
   // two workgroups per CU must fit (two waves per SIMD is what the kernel is compiled for): K <= 65.  Beyond,
   // the one-output kernel is ahead again (72 px: 4.7 vs 5.0 ms per 2048^2).
   return (size_t)(p->size + 7) * p->sep->tile_pitch * sizeof(double) <= 80 * 1024;
