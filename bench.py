@@ -470,6 +470,33 @@ def worker(args):
     }
     if gather is not None:
         result["allgather"] = gather
+    if not args.only_timed_loop and world == 1:
+        # what THIS box sustains on a plain stream over the very buffer the kernel reads (same physical pages), and on a copy
+        # into the buffer it writes: a slow box or an unlucky placement shows here, a bad access pattern only in the kernel
+        real_bytes = (traffic or n_local * (per_patch - 2 * K * 4))          # PMC traffic, else rows 0 / K-1 not fetched
+        try:
+            in_bytes = (patches.numel() * 4 // 262144) * 262144
+            groups = in_bytes // 262144
+            ms_read = _native.hbm_probe(local_rank, patches.data_ptr(), in_bytes)
+            n_copy = min(in_bytes, (full.numel() * 8 // 262144) * 262144)
+            ms_copy = _native.hbm_probe(local_rank, patches.data_ptr(), n_copy, dst_ptr=full.data_ptr())
+            per_group = (full.numel() * 8 // groups) // 16 * 16               # the kernel's own ratio of written to read bytes
+            ms_mix = _native.hbm_probe(local_rank, patches.data_ptr(), in_bytes, dst_ptr=full.data_ptr(), store_per_group=per_group)
+            D.patch_moments_device(plan, patches, out=mine)                    # `full` was the probes' target: restore the moments
+            torch.cuda.synchronize()
+            mix_bytes = in_bytes + groups * per_group
+            result["roofline"]["this_box"] = {
+                "stream_read_GBps": in_bytes / ms_read / 1e6, "copy_GBps": 2 * n_copy / ms_copy / 1e6,
+                "stream_with_the_kernels_store_ratio_GBps": mix_bytes / ms_mix / 1e6,
+                "stream_with_stores_ms_scaled_to_kernel_traffic": ms_mix * real_bytes / mix_bytes,
+                "kernel_ms_median": spread["median"], "kernel_real_traffic_GBps": real_bytes / (spread["median"] * 1e-3) / 1e9,
+                "note": "zk_hbm_probe on the kernel's own buffers, HIP events: LDS-DMA stream read of the batch; 16-B-per-lane "
+                        "copy; the same read stream with the kernel's ratio of stored to read bytes (no arithmetic).  The last "
+                        "one, scaled to the bytes the kernel really moves, is what a bare stream of this traffic mix takes "
+                        "on THIS box: mixing 8.6 % writes into the reads costs far more than their bytes, and by how much "
+                        "differs from box to box (profiles/r03_stream_limits.txt)"}
+        except RuntimeError as exc:
+            result["roofline"]["this_box"] = {"error": str(exc)}
     if not verified:
         # a `value` whose gathered matrix is wrong is not a measurement: keep what was timed under another name, say why,
         # and leave non-zero (every rank takes this branch: `verified` went through max_over_ranks)
@@ -737,8 +764,8 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
     if not args.no_dense:
         out_f = D.frame_moments_device(plan, f_dev)
         npx = H * H
-        strip = n_max <= 8 and (K + 7) * (K + 63) * 8 <= 80 * 1024 and not os.environ.get("ZK_NO_STRIP")
-        flops = rl.strip_flops_per_unit(z.polynomials[0], n_max) if strip else rl.sep_flops_per_unit(z.polynomials[0], n_max)
+        strip = rl.strip2_available(K, n_max) and not os.environ.get("ZK_NO_STRIP")
+        flops = rl.strip2_flops_per_unit(z.polynomials[0], n_max) if strip else rl.sep_flops_per_unit(z.polynomials[0], n_max)
         dense = {"positions": npx, "kernels": {}}
         for path in (_native.PATH_SEPARABLE, _native.PATH_FOLDED):
             if not plan.has_path(1, _native.ZK_F32, path):
@@ -747,7 +774,7 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
             ms, _ = _profiled(plan, lambda: D.frame_moments_device(plan, f_dev, out=out_f), 5)
             entry = {"patches_per_s": npx / (ms * 1e-3), "kernel_ms": ms}
             if path == _native.PATH_SEPARABLE:
-                entry["kernel"] = "zk_frame_strip_kernel" if strip else "zk_frame_sep_kernel"
+                entry["kernel"] = "zk_frame_strip2_kernel" if strip else "zk_frame_sep_kernel"
                 entry["fp64_flops_per_position"] = flops
                 entry["roofline"] = _fp64_roofline(npx * flops, npx * rl.dense_bytes_per_position(n_max), ms)
             else:
@@ -766,8 +793,8 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
         frames = torch.stack([torch.from_numpy(honeycomb_frame(H, seed=1000 + i)) for i in range(per_rank)]).to(dev)
         full = torch.empty((per_rank, n_poly, H, H), dtype=torch.float64, device=dev)
         ms, launches = _profiled(plan, lambda: [D.frame_moments_device(plan, frames[i], out=full[i]) for i in range(per_rank)], 3)
-        strip = n_max <= 8 and (K + 7) * (K + 63) * 8 <= 80 * 1024 and not os.environ.get("ZK_NO_STRIP")
-        flops = rl.strip_flops_per_unit(z.polynomials[0], n_max) if strip else rl.sep_flops_per_unit(z.polynomials[0], n_max)
+        strip = rl.strip2_available(K, n_max) and not os.environ.get("ZK_NO_STRIP")
+        flops = rl.strip2_flops_per_unit(z.polynomials[0], n_max) if strip else rl.sep_flops_per_unit(z.polynomials[0], n_max)
         result["config3_per_gpu"] = {
             "workload": f"configs[3], one GPU's share of the 64-frame batch: {per_rank} synthetic {H}x{H} frames, dense {K}-px moments "
                         f"-> ({per_rank}, {n_poly}, {H}, {H}) float64 ({full.numel() * 8 / 1e9:.1f} GB); N > 1 adds the all-gather "
@@ -812,10 +839,12 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
         torch.cuda.empty_cache()
         od = torch.empty((91, 4096, 4096), dtype=torch.float64, device=dev)
         ms, _ = _profiled(plan12, lambda: D.frame_moments_device(plan12, f2, out=od), 3)
-        flops = rl.sep_flops_per_unit(z12.polynomials[0], 12)
+        strip12 = rl.strip2_available(64, 12) and not os.environ.get("ZK_NO_STRIP") and not os.environ.get("ZK_STRIP_NO_SPLIT")
+        flops = rl.strip2_flops_per_unit(z12.polynomials[0], 12) if strip12 else rl.sep_flops_per_unit(z12.polynomials[0], 12)
         result["config2_dense"] = {
             "workload": "configs[2]: 4096x4096 frame, every 64-px window (zero-padded 'same' positions), n_max=12 -> (91, 4096, 4096) float64",
-            "kernel": "zk_frame_sep_kernel<12>", "kernel_ms": ms, "positions_per_s": 4096 * 4096 / (ms * 1e-3),
+            "kernel": "zk_frame_strip2_kernel<12> (two outputs per lane, two passes by x parity)" if strip12 else "zk_frame_sep_kernel<12>",
+            "kernel_ms": ms, "positions_per_s": 4096 * 4096 / (ms * 1e-3),
             "fp64_flops_per_position": flops,
             "roofline": _fp64_roofline(4096 * 4096 * flops, 4096 * 4096 * rl.dense_bytes_per_position(12), ms)}
         del od, f2, plan12, z12

@@ -448,6 +448,19 @@ int zk_device_free(int device, void* dev);
 int zk_device_copy(int device, void* dst, const void* src, int64_t bytes, int kind /* 1 H2D, 2 D2H, 3 D2D */);
 int zk_device_synchronize(int device);
 
+/* What this GPU sustains on a plain stream over a caller's buffers, measured with HIP events (bench.py prints it beside the
+ * batch kernel's figure, so that a slow box, an unlucky physical placement, or the cost of mixing reads and writes shows as
+ * such).  `bytes` of src_dev are read in 256-KiB groups (rounded down):
+ *   dst_dev == NULL                          every wave reads contiguous 16-KiB stages through the LDS-DMA engine
+ *                                            (global_load_lds nt, the batch kernel's own load instruction) and discards them;
+ *   dst_dev != NULL, store_per_group == 0    a 16-B-per-lane copy src -> dst (non-temporal loads and stores);
+ *   dst_dev != NULL, store_per_group  > 0    the read stream above, and after each group its wave writes store_per_group
+ *                                            bytes (a multiple of 16) to dst_dev + group * store_per_group as 1-KiB
+ *                                            non-temporal runs: the batch kernel's traffic mix without its arithmetic
+ *                                            (23040 = 64 patches x 45 moments per 256 KiB of float32 32-px patches).
+ * *ms_out = average over `reps` launches after one warm-up. */
+int zk_hbm_probe(int device, const void* src_dev, void* dst_dev, int64_t bytes, int64_t store_per_group, int reps, double* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

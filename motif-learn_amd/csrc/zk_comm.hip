@@ -547,6 +547,81 @@ extern "C" int zk_device_copy(int device, void* dst, const void* src, int64_t by
   return 0;
 }
 
+// ---- plain-stream probes (see zernike_hip.h) ---------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(64) void probe_read_kernel(const char* __restrict__ in, long long n_groups, float* __restrict__ sink,
+                                                        char* __restrict__ res, long long store_per_group) {
+  __shared__ __attribute__((aligned(16))) float lds[4096];
+  const int lane = threadIdx.x;
+  float sum = 0.f;
+  for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const char* base = in + g * 262144;
+    for (int s = 0; s < 16; ++s) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + s * 16384 + i * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(lds + i * 256), 16, 0, 2 /* nt */);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      sum += lds[(lane * 7 + s) & 4095];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (res) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      d2* dst = (d2*)(res + g * store_per_group);
+      const d2 v = {(double)sum, 1.0};
+      for (long long k = lane; k < store_per_group / 16; k += 64) __builtin_nontemporal_store(v, dst + k);
+    }
+  }
+  if (sum == 1.2345e-30f) sink[blockIdx.x] = sum;  // keeps the reads alive; never true for real data
+}
+
+typedef float probe_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void probe_copy_kernel(const probe_f4* __restrict__ in, probe_f4* __restrict__ out, long long n16) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+
+}  // namespace
+
+extern "C" int zk_hbm_probe(int device, const void* src, void* dst, int64_t bytes, int64_t store_per_group, int reps, double* ms_out) {
+  if (!src || !ms_out || reps < 1 || bytes < 262144) return zk_fail(ZK_E_BADARG, "need a source, reps >= 1 and at least 256 KiB");
+  if (store_per_group < 0 || store_per_group % 16 || (store_per_group && !dst)) return zk_fail(ZK_E_BADARG, "bad store size");
+  ZK_ON_DEVICE(device);
+  const long long n_groups = bytes / 262144;
+  float* sink = nullptr;
+  ZK_HIP(hipMalloc((void**)&sink, 8192 * sizeof(float)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  auto launch = [&]() {
+    if (dst && !store_per_group)
+      hipLaunchKernelGGL(probe_copy_kernel, dim3(8192), dim3(256), 0, 0, (const probe_f4*)src, (probe_f4*)dst, n_groups * 16384);
+    else
+      hipLaunchKernelGGL(probe_read_kernel, dim3(2048), dim3(64), 0, 0, (const char*)src, n_groups, sink, (char*)dst,
+                         (long long)store_per_group);
+  };
+  float ms = 0.f;
+  if (e == hipSuccess) {
+    launch();
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipEventRecord(e0, 0);
+  if (e == hipSuccess) {
+    for (int k = 0; k < reps; ++k) launch();
+    e = hipEventRecord(e1, 0);
+  }
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  if (e != hipSuccess) return zk_hip_fail(e, "zk_hbm_probe");
+  *ms_out = (double)ms / reps;
+  return 0;
+}
+
 extern "C" int zk_device_synchronize(int device) {
   ZK_ON_DEVICE(device);
   ZK_HIP(hipDeviceSynchronize());

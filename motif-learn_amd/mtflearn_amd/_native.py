@@ -133,6 +133,7 @@ SYMBOLS = {
     "zk_device_free": (c_int, [c_int, c_void_p]),
     "zk_device_copy": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int]),
     "zk_device_synchronize": (c_int, [c_int]),
+    "zk_hbm_probe": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_double)]),
     "zk_plan_profile": (c_int, [c_void_p, c_int]),
     "zk_plan_profile_read": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
     "zk_plan_profile_read_launches": (c_int, [c_void_p, POINTER(c_double), c_int64, POINTER(c_int64)]),
@@ -195,6 +196,16 @@ def device_count():
     if n < 0:
         raise RuntimeError(f"zk_device_count failed with code {n}: {last_error()}")
     return n
+
+
+def hbm_probe(device, src_ptr, nbytes, dst_ptr=None, store_per_group=0, reps=5):
+    """Milliseconds per pass of a plain stream over device buffers (``zk_hbm_probe``): LDS-DMA read of ``nbytes`` at
+    ``src_ptr`` (``dst_ptr`` None), a 16-B-per-lane copy, or the read stream plus ``store_per_group`` bytes written per
+    256-KiB group."""
+    ms = c_double()
+    check(load().zk_hbm_probe(int(device), c_void_p(src_ptr), c_void_p(dst_ptr) if dst_ptr else None, int(nbytes),
+                              int(store_per_group), int(reps), byref(ms)), "zk_hbm_probe")
+    return ms.value
 
 
 def dtype_code(dtype):

@@ -66,6 +66,27 @@ def strip_flops_per_unit(basis0, n_max):
     return (sweep_cols * (2 + 2 * (n_max + 1)) + 2 * disk_rows * 2 * n_poly(n_max) + 2 * 2 * _t_terms(n_max)) / 2
 
 
+def strip2_flops_per_unit(basis0, n_max):
+    """``zk_frame_strip2_kernel`` (round 3; even window sizes, n_max <= 12): per PAIR of vertically adjacent outputs every
+    frame row is swept once from the centre to the wider of the two inner limits -- per column pair a sum, a difference, one
+    add for degree 0 (P_0 = 1 is implicit) and n_max FMAs; with n_max > 8 the even and the odd degrees are done in two passes
+    over the same tile, which executes the same operations -- then every frame row that holds a disk pixel of either output
+    costs two row steps of N_poly slots (n_max + 1 of them adds: P_0(y) = 1), and both outputs share one T product's operands."""
+    mask = basis0 != 0
+    K, Q, _, _ = _disk_geometry(mask)
+    cmin = [int(np.argmax(mask[r, :Q])) if mask[r, :Q].any() else Q for r in range(K)]
+    limits = [min(cmin[fr] if fr < K else Q, cmin[fr - 1] if fr > 0 else Q) for fr in range(K + 1)]
+    sweep_cols = sum(Q - c for c in limits)
+    live_rows = sum(1 for c in limits if c < Q)
+    row_step = 2 * n_poly(n_max) - (n_max + 1)
+    return (sweep_cols * (3 + 2 * n_max) + 2 * live_rows * row_step + 2 * 2 * _t_terms(n_max)) / 2
+
+
+def strip2_available(size, n_max):
+    """Mirror of ``zk_sep_strip_available`` for the round-3 form (bench labels only)."""
+    return size % 2 == 0 and n_max <= 12 and (size + 7) * (size + 63) * 8 <= 80 * 1024
+
+
 def stream_flops_per_unit(basis0, n_max):
     """``zk_patch_stream_kernel``: no mirror folds -- per disk pixel n_max FMAs + 1 add, per disk row N_poly FMAs."""
     mask = basis0 != 0

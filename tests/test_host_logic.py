@@ -262,6 +262,19 @@ def test_product_fails_loudly_without_device():
         ZPs(4, 8).transform(np.zeros((2, 8, 8), dtype=np.float32))
     with pytest.raises(RuntimeError, match="no HIP device"):
         ZPs(4, 8).transform(np.zeros((16, 16), dtype=np.float32))
+    # the consumers too: nothing computes on the CPU (the deviation from SURVEY 8b)
+    from mtflearn_amd.features import pca
+    from mtflearn_amd.clustering import kmeans_lbs
+    X = np.random.default_rng(0).standard_normal((50, 5))
+    with pytest.raises(RuntimeError):
+        pca(X, 2)
+    with pytest.raises(RuntimeError):
+        kmeans_lbs(X, 3)
+    # what does work without a device: the basis, validation, the container's host methods
+    z = ZPs(4, 8)
+    assert z.polynomials.shape == (15, 8, 8)
+    zm = zmoments(np.ones((3, 15)), z.n, z.m)
+    assert zm.to_complex().data.shape == (3, 9) and zm.rot_maps([2, 3]).shape == (3, 2)
 
 
 def test_product_never_imports_the_oracle():
