@@ -418,7 +418,7 @@ double zk_rows_last_kernel_ms(const zk_rows* rows);
 int zk_gmm_estep(zk_rows* rows, const double* prec_chol, const double* means, const double* log_det, const double* log_w, int k,
                  int want_resp, double* lse_sum_out);
 int zk_gmm_resp_from_labels(zk_rows* rows, int k);               /* one-hot of the current labels */
-int zk_gmm_moments(zk_rows* rows, int component, int count, const double* shift, double* gram_out);  /* count 1..3 per pass */
+int zk_gmm_moments(zk_rows* rows, int component, int count, const double* shift, double* gram_out);  /* count 1..8 per pass (1..3 with more than 47 features) */
 /* The same sums with unit weights (the Gram matrix about `shift` with the column sums and N: what a covariance needs). */
 int zk_rows_gram(zk_rows* rows, const double* shift, double* gram_out);
 

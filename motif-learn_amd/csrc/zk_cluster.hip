@@ -655,6 +655,125 @@ __global__ __launch_bounds__(1024) void wgram_kernel(const double* __restrict__ 
   }
 }
 
+// The same sums on the matrix cores (D + 1 <= 48, i.e. the 45 moments of n_max 8 and below): S_c = sum_r w_cr z_r z_r^T is a
+// symmetric rank-N update -- GEMM-shaped work -- and v_mfma_f64_16x16x4_f64 takes both of its operands straight from LDS: one
+// double per lane per operand for 2 048 flops, where the register-tiled kernel above reads eight doubles per 32 flops and is
+// bound by those reads.  All components of a call (KC <= 8) are done in ONE pass over the matrix.
+//   A wave owns ONE of the six 16 x 16 blocks (bi <= bj) of the 48 x 48-padded upper triangle for the whole kernel, with KC
+//   accumulators (4 doubles per lane each), and walks every n-th 64-row tile.  It fetches what IT needs of a tile itself -- the
+//   16 columns of block column bi (and of bj) as two 8-KiB planes [64 rows][16 doubles], and the KC x 64 weights -- with the
+//   LDS-DMA engine into a slab of its own: no workgroup barrier exists (a wave only reads LDS bytes it DMA'd itself), every wave
+//   does the same work, and while one wave of a SIMD waits for its tile the other one's MFMAs run.  (A column block is fetched
+//   by three or four waves: L2 traffic, HBM still sees the matrix once.)
+//   k dimension = rows: step s uses rows 4s .. 4s + 3: A[i][k] = z_{4s+k}[16 bi + i], B[k][j] = w_c[4s+k] z_{4s+k}[16 bj + j]
+//   (lane l: i = j = l & 15, k = l >> 4; tools/micro_mfma64.hip verified the layout).  A plane's row pitch of 128 B puts the
+//   four rows of a step on disjoint halves of the LDS banks.
+//   Measured, six components of 4 M x 45: register-tiled kernel 2.84 ms (two passes of three); this kernel 1.38 ms
+//   (53 TFLOP/s of MFMA work).
+//   What bounds it: SQ_VALU_MFMA_BUSY_CYCLES = 0.70 of the kernel's SIMD cycles at a measured 2.35 GHz -- and the same 0.70 in
+//   three differently organised versions (barrier per tile pair; this one; this one with 32-row stages double-buffered per
+//   wave: 1.43 / 1.38 / 1.48 ms for six components).  On this chip the float64 MFMA and the float64 vector pipe have the
+//   same peak (78.6 TFLOP/s) and evidently do not overlap: the ~14 vector instructions a step needs beside its KC MFMAs (the
+//   weight products, the shift, address updates) take their share of the same cycles.
+template <int KC>
+__global__ __launch_bounds__(256, 2) void wgram_mfma_kernel(const double* __restrict__ X, long long N, int D, int sets,
+                                                            const double* __restrict__ shift, const double* __restrict__ w,
+                                                            double* __restrict__ part) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  constexpr int SLAB = 2 * TILE * 16 + KC * TILE;  // doubles per wave: plane A, plane Z, weights
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long gw = (long long)blockIdx.x * 4 + wv;  // global wave index: set = gw / 6 walks tiles set, set + sets, ...
+  const int blk = (int)(gw % 6);
+  const long long set = gw / 6;
+  if (set >= sets) return;  // (no barrier in this kernel)
+  const int bi = blk < 3 ? 0 : blk < 5 ? 1 : 2, bj = blk < 3 ? blk : blk < 5 ? blk - 2 : 2;
+  double* const pa = lds + wv * SLAB;
+  double* const pz = bi == bj ? pa : pa + TILE * 16;
+  double* const pw = pa + 2 * TILE * 16;
+  const int ci = 16 * bi + (lane & 15), cj = 16 * bj + (lane & 15), kr = lane >> 4;
+  const bool in_i = ci < D, in_j = cj < D;
+  const double one_i = ci == D ? 1.0 : 0.0, one_j = cj == D ? 1.0 : 0.0;  // the constant column of [x | 1], then zero padding
+  const double si = in_i ? shift[ci] : 0.0, sj = in_j ? shift[cj] : 0.0;
+  v4d acc[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  const long long n_tiles = (N + TILE - 1) / TILE;
+  // DMA addressing of a plane: position p = q * 64 + lane (q = 0 .. 7) is granule g = p & 7 (two columns) of row p >> 3; a
+  // granule is fetched when its first column exists (its second one may be the next row's first element: never used).  The
+  // last tile goes through ordinary loads (rows past the end as zeros; and a DMA of its last row could read past the matrix).
+  const int g = lane & 7, rq = lane >> 3;
+  const bool ga = 16 * bi + 2 * g < D, gz = 16 * bj + 2 * g < D;
+  for (long long t = set; t < n_tiles; t += sets) {
+    const long long r0 = t * TILE;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is no longer read
+    if (t + 1 < n_tiles) {
+      const char* rowp = (const char*)(X + (r0 + rq) * D);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const char* src = rowp + (long long)q * 8 * D * 8;
+        if (ga) __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(src + (16 * bi + 2 * g) * 8), ZK_LDS_PTR((char*)pa + q * 1024), 16, 0, 0);
+        if (bi != bj && gz)
+          __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(src + (16 * bj + 2 * g) * 8), ZK_LDS_PTR((char*)pz + q * 1024), 16, 0, 0);
+      }
+      if (w) {
+#pragma unroll
+        for (int q = 0; q * 64 < KC * 32; ++q) {
+          const int p = q * 64 + lane;  // granule p of the [KC][64] weights: component p / 32, rows 2 (p % 32)
+          if (p < KC * 32)
+            __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR((const char*)(w + (long long)(p >> 5) * N + r0) + (p & 31) * 16),
+                                             ZK_LDS_PTR((char*)pw + q * 1024), 16, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) pw[c * TILE + lane] = 1.0;
+      }
+    } else {
+      for (int e = lane; e < TILE * 16; e += 64) {
+        const long long r = r0 + (e >> 4);
+        const int c1 = 16 * bi + (e & 15), c2 = 16 * bj + (e & 15);
+        pa[e] = r < N && c1 < D ? X[r * D + c1] : 0.0;
+        if (bi != bj) pz[e] = r < N && c2 < D ? X[r * D + c2] : 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < KC; ++c) pw[c * TILE + lane] = r0 + lane < N ? (w ? w[(long long)c * N + r0 + lane] : 1.0) : 0.0;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // operands of step s + 1 are read while the MFMAs of step s run (branch-free: the constant columns are selected afterwards)
+    const double* ta = pa + kr * 16 + (lane & 15);
+    const double* tz = pz + kr * 16 + (lane & 15);
+    const double* wt = pw + kr;
+    double a_n = ta[0], z_n = tz[0], w_n[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) w_n[c] = wt[c * TILE];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const double a = in_i ? a_n - si : one_i;
+      const double z = bi == bj ? a : (in_j ? z_n - sj : one_j);
+      double wz[KC];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) wz[c] = w_n[c] * z;
+      if (s + 1 < 16) {
+        a_n = ta[(s + 1) * 64];
+        z_n = tz[(s + 1) * 64];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) w_n[c] = wt[c * TILE + (s + 1) * 4];
+      }
+#pragma unroll
+      for (int c = 0; c < KC; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wz[c], acc[c], 0, 0, 0);
+    }
+  }
+  // this wave's partial block: part[set][blk][c][16 x 16] (row (lane >> 4) + 4 q, column lane & 15)
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    double* out = part + (((long long)set * 6 + blk) * KC + c) * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[(kr + 4 * q) * 16 + (lane & 15)] = acc[c][q];
+  }
+}
+
 // ---- host helpers ------------------------------------------------------------------------------------------------
 // Waves per CU matter more than overlap inside a wave (4 M x 45, two buffers / 3 waves -> one buffer / 6 waves per CU: Lloyd
 // pass with sums 0.67 -> 0.46 ms, labels only 0.45 -> 0.31, seeding 0.41 -> 0.36): two tile buffers (the next tile's DMA under
@@ -1216,6 +1335,54 @@ static int rows_gram(zk_rows* m, const double* w_dev, int count, const double* s
   int rc = upload_tab(m, m->h_buf);
   m->h_buf.clear();
   if (rc) return rc;
+  static const bool no_mfma = getenv("ZK_WGRAM_VALU") != nullptr;  // A/B runs: the register-tiled kernel
+  if (D1 <= 48 && D >= 2 && !no_mfma) {
+    // matrix-core form: every component of the call in one pass; `sets` groups of six waves (one per block of the triangle),
+    // each set walking its share of the tiles
+    const size_t lds = (size_t)4 * (2 * TILE * 16 + count * TILE) * sizeof(double);
+    const long long n_tiles = (m->N + TILE - 1) / TILE;
+    const long long sets = std::max<long long>(1, std::min<long long>(n_tiles, (long long)m->n_cu * 8 / 6));
+    const long long waves = sets * 6, blocks = (waves + 3) / 4;
+    const int n = 6 * count * 256;
+    if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)sets * n * sizeof(double)))) return rc;
+    if ((rc = prof_begin(m))) return rc;
+#define ZK_WGRAM_M(CC)                                                                                                      \
+  {                                                                                                                         \
+    if ((rc = allow_lds(wgram_mfma_kernel<CC>, lds))) return rc;                                                            \
+    hipLaunchKernelGGL(wgram_mfma_kernel<CC>, dim3((unsigned)blocks), dim3(256), lds, m->stream, m->X, (long long)m->N, D,  \
+                       (int)sets, (const double*)m->d_tab, w_dev, (double*)m->d_part);                                      \
+  }
+    switch (count) {
+      case 1: ZK_WGRAM_M(1) break;
+      case 2: ZK_WGRAM_M(2) break;
+      case 3: ZK_WGRAM_M(3) break;
+      case 4: ZK_WGRAM_M(4) break;
+      case 5: ZK_WGRAM_M(5) break;
+      case 6: ZK_WGRAM_M(6) break;
+      case 7: ZK_WGRAM_M(7) break;
+      default: ZK_WGRAM_M(8) break;
+    }
+#undef ZK_WGRAM_M
+    ZK_HIP(hipGetLastError());
+    if ((rc = prof_end(m))) return rc;
+    // fixed-order sum over the sets, then the six blocks are put in place (upper triangle mirrored; inside a diagonal block
+    // only i <= j is taken: its two halves differ in the last bit)
+    std::vector<double> blocks_sum((size_t)n);
+    if ((rc = reduce_to_host(m, (int)sets, n, blocks_sum.data()))) return rc;
+    static const int BI[6] = {0, 0, 0, 1, 1, 2}, BJ[6] = {0, 1, 2, 1, 2, 2};
+    for (int b = 0; b < 6; ++b)
+      for (int c = 0; c < count; ++c) {
+        const double* src = blocks_sum.data() + ((size_t)b * count + c) * 256;
+        double* dst = gram_out + (size_t)c * D1 * D1;
+        for (int i = 0; i < 16; ++i)
+          for (int j = 0; j < 16; ++j) {
+            const int gi = 16 * BI[b] + i, gj = 16 * BJ[b] + j;
+            if (gi < D1 && gj < D1 && gi <= gj) dst[gi * D1 + gj] = dst[gj * D1 + gi] = src[i * 16 + j];
+          }
+      }
+    return prof_read(m);
+  }
+  if (count > 3) return zk_fail(ZK_E_BADARG, "more than 3 components per pass need D <= 47");
   const int threads = std::max(256, (n_ut + 63) & ~63);
   const int G = std::min(threads / n_ut, 16);
   const size_t lds = ((size_t)64 * (4 * T + 4) + 64 * count) * sizeof(double);
@@ -1247,7 +1414,7 @@ static int rows_gram(zk_rows* m, const double* w_dev, int count, const double* s
 // component's weight in the corner.
 extern "C" int zk_gmm_moments(zk_rows* m, int c, int count, const double* shift, double* gram_out) {
   if (!m || !shift || !gram_out) return zk_fail(ZK_E_BADARG, "null pointer");
-  if (count < 1 || count > 3) return zk_fail(ZK_E_BADARG, "1 to 3 components per pass");
+  if (count < 1 || count > 8 || (count > 3 && m && m->D > 47)) return zk_fail(ZK_E_BADARG, "1 to 8 components per pass (1 to 3 with more than 47 features)");
   if (!m->d_resp || c < 0 || (size_t)(c + count) * m->N * sizeof(double) > m->resp_bytes) return zk_fail(ZK_E_BADARG, "no such component");
   ZK_ON_DEVICE(m->device);
   return rows_gram(m, (const double*)m->d_resp + (size_t)c * m->N, count, shift, gram_out);

@@ -153,13 +153,14 @@ class DeviceRows:
 
     def moments(self, component, shift, count=None):
         """Weighted moment matrix of one component, or (``count`` given) of ``count`` consecutive ones -> (count, D+1, D+1);
-        up to three components share one pass over the matrix."""
+        up to eight components share one pass over the matrix (three when there are more than 47 features)."""
         shift = np.ascontiguousarray(shift)
         d1 = self.n_features + 1
         n = 1 if count is None else int(count)
         out = np.empty((n, d1, d1))
-        for c0 in range(0, n, 3):
-            cc = min(3, n - c0)
+        per_pass = 8 if self.n_features <= 47 else 3
+        for c0 in range(0, n, per_pass):
+            cc = min(per_pass, n - c0)
             _native.check(self._lib.zk_gmm_moments(self._h, int(component) + c0, cc, _p(shift), _p(out[c0:c0 + cc])), "zk_gmm_moments")
         return out[0] if count is None else out
 

@@ -86,7 +86,7 @@ static void run_sfma(const char* name, const double* d_tab, int steps, int block
 // AUX: cache policy of the LDS-DMA loads (0 default, 2 nt -- what the batch kernel uses).  STORE_B: bytes of results every
 // wave writes per 64-patch group (0: none; 23040 = 64 x 45 float64 moments, written as 1-KiB non-temporal runs after the
 // group's reads, like the batch kernel's epilogue) into `res`.
-template <bool ROWPAIR, bool HALF = false, int AUX = 0, int STORE_B = 0>
+template <bool ROWPAIR, bool HALF = false, int AUX = 0, int STORE_B = 0, int SPOL = 0>
 __global__ __launch_bounds__(64) void dma_kernel(const float* __restrict__ in, long long n_groups,
                                                  float* __restrict__ out, double* __restrict__ res = nullptr) {
   __shared__ __attribute__((aligned(16))) float lds[4096];
@@ -167,17 +167,17 @@ __global__ __launch_bounds__(256) void write_only_kernel(double* __restrict__ re
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) __builtin_nontemporal_store(v, (d2*)res + i);
 }
 
-template <bool ROWPAIR, bool HALF = false, int AUX = 0, int STORE_B = 0>
+template <bool ROWPAIR, bool HALF = false, int AUX = 0, int STORE_B = 0, int SPOL = 0>
 static void run_dma(const char* name, const float* d_in, long long n_groups, int blocks, float* d_out, double* d_res = nullptr) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((dma_kernel<ROWPAIR, HALF, AUX, STORE_B>), dim3(blocks), dim3(64), 0, 0, d_in, n_groups, d_out, d_res);
+  hipLaunchKernelGGL((dma_kernel<ROWPAIR, HALF, AUX, STORE_B, SPOL>), dim3(blocks), dim3(64), 0, 0, d_in, n_groups, d_out, d_res);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   const int it = 5;
   for (int k = 0; k < it; ++k)
-    hipLaunchKernelGGL((dma_kernel<ROWPAIR, HALF, AUX, STORE_B>), dim3(blocks), dim3(64), 0, 0, d_in, n_groups, d_out, d_res);
+    hipLaunchKernelGGL((dma_kernel<ROWPAIR, HALF, AUX, STORE_B, SPOL>), dim3(blocks), dim3(64), 0, 0, d_in, n_groups, d_out, d_res);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -221,8 +221,13 @@ int main(int argc, char** argv) {
       run_dma<true, false, 2>("row pairs @ 4 KiB, nt", d_in, n_groups, cu * wpc, d_fo);
       run_dma<false, false, 2, 23040>("contiguous nt + 23 KB stores/group", d_in, n_groups, cu * wpc, d_fo, d_res);
       run_dma<true, false, 2, 23040>("row pairs nt + 23 KB stores/group", d_in, n_groups, cu * wpc, d_fo, d_res);
+      run_dma<true, false, 2, 23040, 1>("  stores: default policy", d_in, n_groups, cu * wpc, d_fo, d_res);
+      run_dma<true, false, 2, 23040, 2>("  stores: sc0 sc1", d_in, n_groups, cu * wpc, d_fo, d_res);
+      run_dma<true, false, 2, 23040, 3>("  stores: sc1", d_in, n_groups, cu * wpc, d_fo, d_res);
+      run_dma<true, false, 2, 23040, 4>("  stores: sc0 sc1 nt", d_in, n_groups, cu * wpc, d_fo, d_res);
+      run_dma<true, false, 2, 23040>("  stores: nt (again)", d_in, n_groups, cu * wpc, d_fo, d_res);
     }
-    {
+    if (false) {
       printf("--- F: stores in chip-wide phases (2048 persistent waves, bounded-spin barrier) ---\n");
       unsigned* d_cnt;
       CK(hipMalloc((void**)&d_cnt, 4));

@@ -42,7 +42,15 @@ timed(f"lloyd pass, k = {k}, labels only", lambda: rows.lloyd(c0, False))
 prec = np.tile(np.eye(D), (k, 1, 1)); logdet = np.zeros(k); logw = np.full(k, -np.log(k))
 timed(f"mixture E step, k = {k}", lambda: rows.estep(prec, centres, logdet, logw))
 timed("mixture moments, one component", lambda: rows.moments(0, mean))
-timed(f"mixture moments, all {k} (3 per pass)", lambda: rows.moments(0, mean, count=k))
+timed(f"mixture moments, all {k} in one call", lambda: rows.moments(0, mean, count=k))
+rows.profile(True)
+for label, fn in (("E step", lambda: rows.estep(prec, centres, logdet, logw)), ("moments, one component", lambda: rows.moments(0, mean)),
+                  (f"moments, all {k}", lambda: rows.moments(0, mean, count=k)), ("lloyd with sums", lambda: rows.lloyd(c0, True))):
+    fn(); ms = []
+    for _ in range(5):
+        fn(); ms.append(rows.last_kernel_ms())
+    print(f"  kernel only (HIP events): {label:28s} {sorted(ms)[2]:8.3f} ms")
+rows.profile(False)
 t0 = time.perf_counter(); lab, _, it = kmeans_fit(rows, k, 0); t_km = time.perf_counter() - t0
 print(f"kmeans_fit: {t_km * 1e3:.0f} ms, {it} iterations")
 t0 = time.perf_counter(); lab2, it2, conv = gmm_fit_predict(rows, k, "full", 0); t_gm = time.perf_counter() - t0
