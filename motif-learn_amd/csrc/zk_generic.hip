@@ -13,6 +13,11 @@
 // order -- the definition both reference paths approximate (_zps.py:155, :165-178).
 #include "zk_internal.h"
 
+#ifndef ZK_GEN_PB
+#define ZK_GEN_PB 8  // pixels in flight per lane
+#endif
+#define ZK_TAB __attribute__((address_space(4)))
+
 namespace {
 
 template <typename T, int MODE, int CHUNK>  // MODE 0: batch of patches, 1: dense frame; CHUNK: functions per pass
@@ -33,25 +38,38 @@ __global__ __launch_bounds__(256) void zk_generic_kernel(
     base = in + (live ? u : 0) * (long long)size * size;
   }
 
+  const ZK_TAB int* cpix = (const ZK_TAB int*)pix;        // wave-uniform tables through the constant address space:
+  const ZK_TAB double* ctab = (const ZK_TAB double*)tab;  // always scalar loads
   for (int c = 0; c < n_chunks; ++c) {
     double acc[CHUNK];
 #pragma unroll
     for (int j = 0; j < CHUNK; ++j) acc[j] = 0.0;
-    const double* __restrict__ row = tab + (size_t)c * npx * CHUNK;
-    for (int t = 0; t < npx; ++t) {
-      const int2 rc = pix[t];
-      double f;
-      if (MODE == 1) {
-        const int ii = oi - ea + rc.x;
-        const int kk = ok - ea + rc.y;
-        const bool inside = live && ii >= 0 && ii < H && kk >= 0 && kk < W;
-        f = inside ? (double)in[(long long)ii * W + kk] : 0.0;
-      } else {
-        f = (double)base[rc.x * size + rc.y];
-      }
-      const double* __restrict__ b = row + (size_t)t * CHUNK;
+    const ZK_TAB double* __restrict__ row = ctab + (size_t)c * npx * CHUNK;
+    // ZK_GEN_PB pixels are requested before the first of them is used: written one pixel at a time, every pixel exposed a
+    // whole memory latency (uncoalesced in batch mode) in front of its CHUNK FMAs -- 3 % of the FP64 peak at n_max 36
+    // (profiles/r03_high_orders.txt).  Same pixels in the same order: results are bit-identical.
+    for (int t0 = 0; t0 < npx; t0 += ZK_GEN_PB) {
+      double f[ZK_GEN_PB];
 #pragma unroll
-      for (int j = 0; j < CHUNK; ++j) acc[j] = __builtin_fma(f, b[j], acc[j]);
+      for (int q = 0; q < ZK_GEN_PB; ++q) {
+        const int t = t0 + q < npx ? t0 + q : npx - 1;  // (wave-uniform) past the end: the last pixel again, weighted 0 below
+        const int rcx = cpix[2 * t], rcy = cpix[2 * t + 1];
+        if (MODE == 1) {
+          const int ii = oi - ea + rcx;
+          const int kk = ok - ea + rcy;
+          const bool inside = live && ii >= 0 && ii < H && kk >= 0 && kk < W && t0 + q < npx;
+          f[q] = inside ? (double)in[(long long)ii * W + kk] : 0.0;
+        } else {
+          f[q] = t0 + q < npx ? (double)base[rcx * size + rcy] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < ZK_GEN_PB; ++q) {
+        const int t = t0 + q < npx ? t0 + q : npx - 1;
+        const ZK_TAB double* __restrict__ b = row + (size_t)t * CHUNK;
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) acc[j] = __builtin_fma(f[q], b[j], acc[j]);
+      }
     }
     if (live) {
 #pragma unroll

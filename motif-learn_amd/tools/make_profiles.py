@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 TOOL = os.path.join(ROOT, "motif-learn_amd", "tools", "pmc_summary.py")
 
@@ -58,21 +58,21 @@ for line in sq.splitlines():
     m = re.match(r"(\S.*?)\s+(SQ_\w+)\s+launches=\s*(\d+) mean=\s*([\d.]+)", line)
     if m:
         vals[m.group(1).strip()][m.group(2)] = float(m.group(4))
-waves = {"zk_frame_strip_kernel<8, float>": 2, "zk_frame_sep_kernel<12, float, 15>": 2, "zk_frame_maps_kernel<10, float>": 2,
+waves = {"zk_frame_strip_kernel<8, float>": 2, "zk_frame_strip2_kernel<8, float, 16>": 2, "zk_frame_strip2_kernel<12, float, 32>": 2,
+         "zk_frame_sep_kernel<12, float, 15>": 2, "zk_frame_maps_kernel<10, float>": 2,
          "zk_patch_sep_kernel<12, 8, float, true, 15>": 1, "zk_patch_stream_kernel<12, float>": 2}
 with open(os.path.join(P, f"{TAG}_sq_counters.txt"), "w") as f:
     f.write(f"""# {TAG}: SQ counters of the dense / maps / (64, 12) batch kernels (rocprofv3 --pmc, two counter sets in separate passes;
 # motif-learn_amd/tools/profile_round.sh -> tools/run_dense.py; means over 3 launches, summed over the chip).
-# Workloads: strip<8>: 2048^2 frame, 32-px; frame_sep<12>: 4096^2, 64-px; maps<10>: 4096^2, 32-px, all outputs;
-#            patch_sep<12,...,wide> / stream<12>: 1.0 M 64-px float32 patches.
+# Workloads: strip2<8>: 2048^2 frame, 32-px; strip2<12> (round 3: two passes by x parity; round 2 ran frame_sep<12> here):
+#            4096^2, 64-px; maps<10>: 4096^2, 32-px, all outputs; patch_sep<12,...,wide> / stream<12>: 1.0 M 64-px float32 patches.
 # Units: SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count in quad-cycles per wave (a wave64 VALU instruction occupies its
 # SIMD for one quad = 4 clocks, so SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU here).
 # derived:  valu_per_wave = ACTIVE_INST_VALU / WAVE_CYCLES  (fraction of a wave's life spent issuing VALU)
 #           simd_valu_busy ~= valu_per_wave x resident waves per SIMD (from the launch bounds)
 #           salu:valu = INSTS_SALU / INSTS_VALU ;  wait_any = WAIT_ANY / WAVE_CYCLES ; wait_inst = WAIT_INST_ANY / WAVE_CYCLES
-# Before this round's scalar-operand pipelining (same counters, kernels of round 1; valu_per_wave / wait_any):
-#   maps<10> 0.306 / 0.48   frame_sep<12> 0.397 / 0.30 (unchanged: not pipelined)   strip<8> 0.323 / 0.32 (unchanged)
-#   patch_sep<12, wide> 0.312 / 0.40   stream<12> 0.297 / 0.36 (unchanged)
+# Round 2 (profiles/r02_sq_counters.txt), same workloads: strip<8> simd_valu_busy 0.625, salu:valu 0.395, wait_any 0.326;
+#   frame_sep<12> 0.81 / 0.18 / 0.30; maps<10> 0.81; patch_sep<12, wide> 0.53 (one wave per SIMD).
 #
 """)
     f.write(f"{'kernel':46s} {'waves/SIMD':>10s} {'valu_per_wave':>13s} {'simd_valu_busy':>14s} {'salu:valu':>9s} {'wait_any':>8s} {'wait_inst':>9s} {'lds_conflict':>12s} {'smem/valu':>9s}\n")

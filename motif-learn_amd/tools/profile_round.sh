@@ -4,7 +4,7 @@
 # (3) SQ counters of the dense / maps / (64, 12) batch kernels, two counter sets in their own passes
 # (4) kernel trace of the clustering consumers
 # Everything lands under gpurun_out/<tag>_*; summaries are made afterwards with tools/pmc_summary.py and copied to profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 set -e
