@@ -142,6 +142,7 @@ extern "C" void zk_plan_destroy(zk_plan* p) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   zk_fold_free(p);
   zk_sep_free(p);
+  zk_direct_free(p);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   if (p->d_pix) (void)hipFree(p->d_pix);
   if (p->d_gen_tab) (void)hipFree(p->d_gen_tab);
@@ -185,6 +186,7 @@ extern "C" int zk_plan_create(int size, int n_poly, const int32_t* n, const int3
   if (!rc) rc = build_generic_tables(p, basis);
   if (!rc) rc = zk_fold_build(p, basis);
   if (!rc) rc = zk_sep_build(p, basis);
+  if (!rc && !p->sep) rc = zk_direct_build(p, basis);  // large sets the polynomial kernels do not take (n_max > 24)
   if (rc) {
     std::string keep = g_last_error;
     zk_plan_destroy(p);
@@ -263,6 +265,9 @@ extern "C" int zk_transform_patches_dev(zk_plan* p, const void* patches, int dty
   if (path < 0) return zk_fail(ZK_E_BADARG, "the forced kernel path is not available for this plan / dtype");
   if (path == ZK_PATH_SEPARABLE) return zk_launch_sep_patches(p, patches, dtype, n_patches, out, s);
   if (path == ZK_PATH_STREAM) return zk_launch_sep_stream(p, patches, dtype, n_patches, out, s);
+  // the plain sum over the caller's numbers: DMA-staged form for large sets (ZK_NO_DIRECT keeps the per-lane loads: A/B, tests)
+  if (zk_direct_patches_available(p, dtype) && n_patches >= 64 && !getenv("ZK_NO_DIRECT"))
+    return zk_launch_direct_patches(p, patches, dtype, n_patches, out, s);
   return zk_launch_generic_patches(p, patches, dtype, n_patches, out, s);
 }
 

@@ -48,10 +48,13 @@ __global__ __launch_bounds__(256) void zk_generic_kernel(
     // ZK_GEN_PB pixels are requested before the first of them is used: written one pixel at a time, every pixel exposed a
     // whole memory latency (uncoalesced in batch mode) in front of its CHUNK FMAs -- 3 % of the FP64 peak at n_max 36
     // (profiles/r03_high_orders.txt).  Same pixels in the same order: results are bit-identical.
-    for (int t0 = 0; t0 < npx; t0 += ZK_GEN_PB) {
-      double f[ZK_GEN_PB];
+    // (dense mode only: in batch mode the lanes' loads are one patch apart, eight of them in flight per lane thrash the
+    //  L1 -- 1.32 -> 0.71 M patches/s at (28, 56); batches of these orders go through zk_direct_patches.hip)
+    constexpr int PB = MODE == 1 ? ZK_GEN_PB : 1;
+    for (int t0 = 0; t0 < npx; t0 += PB) {
+      double f[PB];
 #pragma unroll
-      for (int q = 0; q < ZK_GEN_PB; ++q) {
+      for (int q = 0; q < PB; ++q) {
         const int t = t0 + q < npx ? t0 + q : npx - 1;  // (wave-uniform) past the end: the last pixel again, weighted 0 below
         const int rcx = cpix[2 * t], rcy = cpix[2 * t + 1];
         if (MODE == 1) {
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void zk_generic_kernel(
         }
       }
 #pragma unroll
-      for (int q = 0; q < ZK_GEN_PB; ++q) {
+      for (int q = 0; q < PB; ++q) {
         const int t = t0 + q < npx ? t0 + q : npx - 1;
         const ZK_TAB double* __restrict__ b = row + (size_t)t * CHUNK;
 #pragma unroll

@@ -42,6 +42,9 @@ struct zk_plan {
   // ---- row-separable tables (fastest kernels) ----------------------------------------
   zk_sep_tables* sep = nullptr;    // nullptr when the basis is not the standard polynomial set
 
+  // ---- large sets, batch mode: DMA-staged direct sums, CH functions per launch (zk_direct_patches.hip) ----
+  struct zk_direct_tables* direct = nullptr;  // nullptr below 128 functions
+
   // ---- execution state -------------------------------------------------------------
   hipStream_t stream = nullptr;  // owned; host-variant calls and default for *_dev
   struct zk_host_ring* ring = nullptr;  // staging of the host-buffer entry points (zk_host.hip)
@@ -153,6 +156,10 @@ int zk_sep_build(zk_plan* p, const double* basis);   // fills p->sep or leaves i
 void zk_sep_free(zk_plan* p);
 bool zk_sep_frame_available(const zk_plan* p, int dtype);
 bool zk_sep_patches_available(const zk_plan* p, int dtype);
+int zk_direct_build(zk_plan* p, const double* basis);  // zk_direct_patches.hip
+void zk_direct_free(zk_plan* p);
+bool zk_direct_patches_available(const zk_plan* p, int dtype);
+int zk_launch_direct_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s);
 bool zk_sep_strip_available(const zk_plan* p, int dtype);   // zk_sep_strip.hip: dense, n_max <= 8, two outputs per lane
 int zk_launch_sep_strip(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                         double* out, hipStream_t s);

@@ -11,14 +11,14 @@ from mtflearn_amd import ZPs, _native, distributed as D
 from mtflearn_amd.synthetic import honeycomb_frame
 
 torch.cuda.set_device(0)
-f = torch.from_numpy(honeycomb_frame(1024, seed=0)).cuda()
+f = torch.from_numpy(honeycomb_frame(2048, seed=0)).cuda()
 for n_max, K in ((24, 56), (28, 56), (32, 64), (36, 72)):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         z = ZPs(n_max, K)
     plan = z._device_plan()
-    n = 1 << 15
-    p = f.unfold(0, K, 7).unfold(1, K, 7).reshape(-1, K, K)[:n].contiguous()
+    n = 1 << 17
+    p = f.unfold(0, K, 5).unfold(1, K, 5).reshape(-1, K, K)[:n].contiguous()
     out = D.patch_moments_device(plan, p)
     torch.cuda.synchronize()
     plan.profile(True)
@@ -37,5 +37,5 @@ for n_max, K in ((24, 56), (28, 56), (32, 64), (36, 72)):
     plan.profile(False)
     kern = _native.PATH_NAMES[plan.best_path(0, _native.ZK_F32)]
     print(f"n_max {n_max:2d} K {K:3d} ({len(z.n)} moments)  batch [{kern}]: {p.shape[0] / ms_b / 1e3:8.2f} M patches/s   "
-          f"dense [{_native.PATH_NAMES[plan.best_path(1, _native.ZK_F32)]}]: {band * 1024 / ms_f / 1e3:8.2f} M positions/s", flush=True)
+          f"dense [{_native.PATH_NAMES[plan.best_path(1, _native.ZK_F32)]}]: {band * 2048 / ms_f / 1e3:8.2f} M positions/s", flush=True)
     del out, o2, p
