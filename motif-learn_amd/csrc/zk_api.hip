@@ -290,6 +290,8 @@ extern "C" int zk_transform_frame_dev(zk_plan* p, const void* image, int dtype, 
     return zk_launch_sep_strip(p, image, dtype, H, W, row0, n_rows, out, s);
   if (path == ZK_PATH_SEPARABLE) return zk_launch_sep_frame(p, image, dtype, H, W, row0, n_rows, out, s);
   if (path == ZK_PATH_FOLDED) return zk_launch_fast_frame(p, image, dtype, H, W, row0, n_rows, out, s);
+  if (zk_direct_frame_available(p, dtype) && !getenv("ZK_NO_DIRECT"))  // large sets: the same plain sum on the matrix cores
+    return zk_launch_direct_frame(p, image, dtype, H, W, row0, n_rows, out, s);
   return zk_launch_generic_frame(p, image, dtype, H, W, row0, n_rows, out, s);
 }
 

@@ -45,6 +45,11 @@ struct zk_direct_tables {
     zk_direct_unit* d_units = nullptr;
     double* d_tab = nullptr;  // [n_chunks][n_units][4 runs x UP slots][CH]
   } t[2];                     // [0] float32 (UP = 16 pixels per run), [1] float64 (UP = 8)
+  // dense mode: the disk rows in pieces of 4 consecutive pixels (a piece = one MFMA step)
+  int n_steps = 0;
+  int tile_pitch = 0;
+  int32_t* d_step_off = nullptr;  // [n_steps] tile element offset of the piece's first pixel (window row r: r * tile_pitch + c)
+  double* d_ftab = nullptr;       // [n_chunks][n_steps][4][CH]
 };
 
 namespace {
@@ -189,6 +194,101 @@ int launch_t(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStre
   return 0;
 }
 
+// Dense mode of the same sum: 8 output rows x 64 columns per workgroup, the zero-padded tile staged once in LDS (in the
+// image's own element type) and walked once per chunk; wave = one output row = 64 positions (4 blocks of 16) x CH functions.
+// A step = 4 consecutive pixels of a disk row: A[i][k] = tile[window origin of position 16 pb + i + piece offset + k].
+template <typename TIN>
+__global__ __launch_bounds__(512) void zk_frame_direct_kernel(const TIN* __restrict__ img, double* __restrict__ out,
+                                                               const int32_t* __restrict__ step_off, const double* __restrict__ tab,
+                                                               int n_steps, int n_chunks, int n_poly, int K, int H, int W, int row0,
+                                                               int n_rows, int tile_pitch, long long plane) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  TIN* const tile = (TIN*)lds;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ea = K - 1 - (K - 1) / 2;
+  const int i0 = row0 + blockIdx.y * 8, k0 = blockIdx.x * 64;
+  const int tile_rows = K + 7;
+  for (int tr = wave; tr < tile_rows; tr += 8) {
+    const int ii = i0 - ea + tr;
+    for (int tc0 = 0; tc0 < tile_pitch; tc0 += 256) {
+      TIN v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int tc = tc0 + q * 64 + lane, kk = k0 - ea + tc;
+        v[q] = (TIN)0;
+        if (tc < tile_pitch && ii >= 0 && ii < H && kk >= 0 && kk < W) v[q] = img[(long long)ii * W + kk];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (tc0 + q * 64 + lane < tile_pitch) tile[tr * tile_pitch + tc0 + q * 64 + lane] = v[q];
+    }
+  }
+  __syncthreads();
+
+  const int li = lane & 15, kr = lane >> 4;
+  const TIN* __restrict__ mine = tile + wave * tile_pitch + li + kr;  // (+ 16 pb + piece offset)
+  const ZK_CONST int32_t* soff = zk_const(step_off);
+  const int oi = i0 + wave;
+  const bool row_live = oi < row0 + n_rows;
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    v4d acc[4][FB];
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = v4d{0.0, 0.0, 0.0, 0.0};
+    const double* __restrict__ tl = tab + ((size_t)ch * n_steps * 4 + kr) * CH + li;
+    for (int st = 0; st < n_steps; ++st) {
+      const TIN* __restrict__ px = mine + soff[st];
+      double av[4], bv[FB];
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) av[pb] = (double)px[16 * pb];
+      const double* __restrict__ tr = tl + (size_t)st * 4 * CH;
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) bv[fb] = tr[16 * fb];
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb], bv[fb], acc[pb][fb], 0, 0, 0);
+    }
+    if (row_live) {
+      const int n_live = n_poly - ch * CH < CH ? n_poly - ch * CH : CH;
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) {
+        const bool col_live = 16 * fb + li < n_live;
+        double* __restrict__ dst = out + (long long)(ch * CH + 16 * fb + li) * plane + (long long)(oi - row0) * W + k0;
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ok = 16 * pb + kr + 4 * q;
+            if (col_live && k0 + ok < W) dst[ok] = acc[pb][fb][q];
+          }
+      }
+    }
+  }
+}
+
+template <typename TIN>
+int launch_frame_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out, hipStream_t s) {
+  const zk_direct_tables* d = p->direct;
+  const size_t lds = (size_t)(p->size + 7) * d->tile_pitch * sizeof(TIN);
+  auto kern = zk_frame_direct_kernel<TIN>;
+  if (lds > 64 * 1024)
+    ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long long plane = zk_out_plane(p, n_rows, W);
+  return zk_for_row_bands(row0, n_rows, W, 8, [&](int64_t r0, int64_t nr, long long off) {
+    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((nr + 7) / 8));
+    int rc = zk_prof_begin(p, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const TIN*)in, out + off, d->d_step_off, d->d_ftab, d->n_steps, d->n_chunks,
+                       p->n_poly, p->size, (int)H, (int)W, (int)r0, (int)nr, d->tile_pitch, plane);
+    ZK_HIP(hipGetLastError());
+    return zk_prof_end(p, s);
+  });
+}
+
 }  // namespace
 
 void zk_direct_free(zk_plan* p) {
@@ -198,6 +298,8 @@ void zk_direct_free(zk_plan* p) {
     if (t.d_units) (void)hipFree(t.d_units);
     if (t.d_tab) (void)hipFree(t.d_tab);
   }
+  if (d->d_step_off) (void)hipFree(d->d_step_off);
+  if (d->d_ftab) (void)hipFree(d->d_ftab);
   delete d;
   p->direct = nullptr;
 }
@@ -272,11 +374,58 @@ int zk_direct_build(zk_plan* p, const double* basis) {
     if (!rc) rc = upload(&t.d_tab, tab);
     if (rc) return rc;
   }
+  // ---- dense mode: disk rows in pieces of 4 consecutive pixels (the tile row has 63 spare columns: a piece may run past the
+  // window's last column, its extra slots own nothing)
+  {
+    d->tile_pitch = K + 63;
+    std::vector<int32_t> soff;
+    std::vector<int> owner;  // [step][4]
+    for (int r = 0; r < K; ++r)
+      for (int c = 0; c < K;) {
+        if (!act[(size_t)r * K + c]) {
+          ++c;
+          continue;
+        }
+        soff.push_back(r * d->tile_pitch + c);
+        for (int k = 0; k < 4; ++k) owner.push_back(c + k < K && act[(size_t)r * K + c + k] ? r * K + c + k : -1);
+        c += 4;
+      }
+    std::vector<int> cover((size_t)K * K, 0);
+    for (int o : owner)
+      if (o >= 0) ++cover[o];
+    for (int t = 0; t < K * K; ++t)
+      if (cover[t] != (act[t] ? 1 : 0)) {
+        zk_direct_free(p);
+        return zk_fail(ZK_E_BADARG, "internal: direct dense pieces do not tile the disk");
+      }
+    d->n_steps = (int)soff.size();
+    std::vector<double> ftab((size_t)d->n_chunks * owner.size() * CH, 0.0);
+    for (int c = 0; c < d->n_chunks; ++c)
+      for (size_t k = 0; k < owner.size(); ++k) {
+        if (owner[k] < 0) continue;
+        double* dst = &ftab[((size_t)c * owner.size() + k) * CH];
+        for (int i = 0; i < CH && c * CH + i < NP; ++i) dst[i] = basis[(size_t)(c * CH + i) * K * K + owner[k]] * inv_area;
+      }
+    int rc = upload(&d->d_step_off, soff);
+    if (!rc) rc = upload(&d->d_ftab, ftab);
+    if (rc) return rc;
+  }
   return 0;
 }
 
 bool zk_direct_patches_available(const zk_plan* p, int dtype) {
   return p->direct && p->direct->t[dtype == ZK_F32 ? 0 : 1].n_units > 0;
+}
+
+bool zk_direct_frame_available(const zk_plan* p, int dtype) {
+  return p->direct && p->direct->n_steps > 0 &&
+         (size_t)(p->size + 7) * p->direct->tile_pitch * (dtype == ZK_F32 ? 4 : 8) <= 150 * 1024;
+}
+
+int zk_launch_direct_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out,
+                           hipStream_t s) {
+  if (dtype == ZK_F32) return launch_frame_t<float>(p, in, H, W, row0, n_rows, out, s);
+  return launch_frame_t<double>(p, in, H, W, row0, n_rows, out, s);
 }
 
 int zk_launch_direct_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s) {

@@ -160,6 +160,9 @@ int zk_direct_build(zk_plan* p, const double* basis);  // zk_direct_patches.hip
 void zk_direct_free(zk_plan* p);
 bool zk_direct_patches_available(const zk_plan* p, int dtype);
 int zk_launch_direct_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s);
+bool zk_direct_frame_available(const zk_plan* p, int dtype);
+int zk_launch_direct_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out,
+                           hipStream_t s);
 bool zk_sep_strip_available(const zk_plan* p, int dtype);   // zk_sep_strip.hip: dense, n_max <= 8, two outputs per lane
 int zk_launch_sep_strip(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                         double* out, hipStream_t s);
