@@ -185,3 +185,37 @@ def test_symmetry_scores_of_the_full_moment_matrix():
     at = z.symmetry_at(frame, np.column_stack([kk + 16, ii + 16]))       # (x, y) of the same windows
     rel_close(at["rot_maps"], got["rot_maps"][pick], rtol=1e-6, atol_scale=1e-9)
     rel_close(at["mirror_map"], got["mirror_map"][pick], rtol=1e-6, atol_scale=1e-9)
+
+
+def test_one_ranks_share_of_the_frame_batch():
+    """configs[3] at one rank's FULL share: 8 frames of 2048^2 -> (8, 45, 2048, 2048) float64 (12.1 GB) through the product's
+    driver `sharded_frames_moments` on the library's RCCL communicator (world 1 here; worlds 2-4: tests/test_gpu_multirank.py).
+    Every frame must equal the dense kernel's own result bit for bit (the driver writes in place into the gathered array), and
+    oracle positions of the first and the last frame -- zero-padded borders included -- must match."""
+    import torch
+    from oracle import zernike_oracle as zo
+    from mtflearn_amd import _native, distributed as D
+    from mtflearn_amd.synthetic import honeycomb_frame
+    H, K, n_max, per_rank = 2048, 32, 8, 8
+    z = _zps(n_max, K)
+    plan = z._device_plan()
+    dev = torch.device("cuda:0")
+    host = [honeycomb_frame(H, seed=1000 + i) for i in range(per_rank)]
+    frames = torch.stack([torch.from_numpy(f) for f in host]).to(dev)
+    comm = D.RcclComm(0, 0, 1, unique_id=_native.Comm.unique_id())
+    try:
+        full = torch.full((per_rank, len(z.n), H, H), float("nan"), dtype=torch.float64, device=dev)
+        D.sharded_frames_moments(plan, comm, frames, per_rank, out=full)
+        torch.cuda.synchronize()
+    finally:
+        comm.close()
+    assert torch.isfinite(full).all()
+    one = torch.empty((len(z.n), H, H), dtype=torch.float64, device=dev)
+    for i in range(per_rank):
+        D.frame_moments_device(plan, frames[i], out=one)
+        assert torch.equal(one, full[i]), i
+    rng = np.random.default_rng(31)
+    rows, cols = _positions(H, K, rng)
+    ri, ci = torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev)
+    for i in (0, per_rank - 1):
+        rel_close(full[i][:, ri, ci].T.cpu().numpy(), _oracle_at(zo, host[i], z, rows, cols))

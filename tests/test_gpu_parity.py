@@ -746,3 +746,46 @@ def test_config3_and_config5_sizes(native, zo):
                       atol_scale=1e-11)
             rel_close(mir[ri, ci].cpu().numpy(), zo.mirror_map(ref, z.n, z.m), rtol=1e-8, atol_scale=1e-11)
             del rot, ab, mir
+
+
+@pytest.mark.parametrize("n_max,size,dtype", [(28, 56, np.float32), (25, 26, np.float64), (36, 72, np.float32)])
+def test_large_sets_two_implementations_of_the_plain_sum(native, zo, n_max, size, dtype, monkeypatch):
+    """n_max 25-40: the matrix-core kernels of zk_direct_patches.hip and the per-lane generic kernel (ZK_NO_DIRECT=1) are two
+    independent implementations of the same unfolded sum over the caller's basis values; both must match the oracle, batch and
+    dense, ragged counts and borders included."""
+    rng = np.random.default_rng(n_max * 7 + size)
+    z = _zps(n_max, size)
+    plan = z._device_plan()
+    assert not plan.has_path(0, native.ZK_F32, native.PATH_SEPARABLE)
+    p = (rng.random((64 + 64 + 13, size, size)) - 0.4).astype(dtype)          # two whole waves and a ragged one
+    img = (rng.random((size + 9, size + 70)) - 0.5).astype(dtype)
+    ref_p = zo.moments_patches(p, z.polynomials)
+    ref_f = zo.moments_frame_direct(img, z.polynomials)
+    got = {}
+    for label, env in (("direct", None), ("per-lane", "1")):
+        if env:
+            monkeypatch.setenv("ZK_NO_DIRECT", env)
+        else:
+            monkeypatch.delenv("ZK_NO_DIRECT", raising=False)
+        got[label] = (z.transform(p).data.copy(), z.transform(img).data.copy())
+        rel_close(got[label][0], ref_p)
+        rel_close(got[label][1], ref_f)
+    monkeypatch.delenv("ZK_NO_DIRECT", raising=False)
+    for a, b in zip(got["direct"], got["per-lane"]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-13 * np.abs(b).max())
+
+
+def test_hbm_probe_reports_plausible_stream_rates(native):
+    """zk_hbm_probe (bench.py roofline.this_box): read stream, copy and read stream with stores, on 1 GiB."""
+    import torch
+    src = torch.zeros(1 << 28, dtype=torch.float32, device="cuda")                 # 1 GiB
+    dst = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+    n = src.numel() * 4
+    ms_read = native.hbm_probe(0, src.data_ptr(), n)
+    ms_copy = native.hbm_probe(0, src.data_ptr(), n, dst_ptr=dst.data_ptr())
+    ms_mix = native.hbm_probe(0, src.data_ptr(), n, dst_ptr=dst.data_ptr(), store_per_group=23040)
+    for ms in (ms_read, ms_copy, ms_mix):
+        assert 0.05 < ms < 5.0                                                     # 0.2 .. 20 TB/s: a timing, not a constant
+    assert ms_read <= ms_mix * 1.05
+    with pytest.raises(RuntimeError, match="zk_hbm_probe"):
+        native.hbm_probe(0, src.data_ptr(), 1000)
