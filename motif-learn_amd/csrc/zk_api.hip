@@ -143,6 +143,8 @@ extern "C" void zk_plan_destroy(zk_plan* p) {
   zk_fold_free(p);
   zk_sep_free(p);
   zk_direct_free(p);
+  for (auto& e : p->trig_cache)
+    if (e.dev) (void)hipFree(e.dev);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   if (p->d_pix) (void)hipFree(p->d_pix);
   if (p->d_gen_tab) (void)hipFree(p->d_gen_tab);

@@ -71,15 +71,9 @@ struct zk_set {
     return -1;
   }
   // index of the complex moment (n, |m|) in the reference's to_complex() order (n, then m ascending)
-  static constexpr int complex_index(int n, int am) {
-    int k = 0;
-    for (int nn = 0; nn <= NMAX; ++nn)
-      for (int mm = nn & 1; mm <= nn; mm += 2) {
-        if (nn == n && mm == am) return k;
-        ++k;
-      }
-    return -1;
-  }
+  // (closed form: orders below n hold floor(n'/2) + 1 entries each.  The planes / rows kernels call this with a RUN-TIME n --
+  //  the counting loop it used to be ran as scalar code in front of every |Z| store: 2.9 of 3.2 ms per 128 x 2048 band at n_max 24)
+  static constexpr int complex_index(int n, int am) { return ((n + 1) >> 1) * ((n + 2) >> 1) + ((am - (n & 1)) >> 1); }
   static constexpr int NC = complex_index(NMAX, NMAX) + 1;
   static constexpr int complex_n(int k) {
     int i = 0;

@@ -45,6 +45,16 @@ struct zk_plan {
   // ---- large sets, batch mode: DMA-staged direct sums, CH functions per launch (zk_direct_patches.hip) ----
   struct zk_direct_tables* direct = nullptr;  // nullptr below 128 functions
 
+  // ---- symmetry maps: fold weights + cos / sin(m theta) (zk_sep_maps.hip).  One device table per distinct
+  // (folds, m_unselect, theta) option set, kept for the life of the plan (a few KiB each, at most
+  // ZK_TRIG_CACHE of them): a repeated call uploads nothing and never synchronises, and a launch in flight
+  // never sees its table overwritten.
+  struct trig_entry {
+    std::vector<double> host;
+    double* dev = nullptr;
+  };
+  std::vector<trig_entry> trig_cache;
+
   // ---- execution state -------------------------------------------------------------
   hipStream_t stream = nullptr;  // owned; host-variant calls and default for *_dev
   struct zk_host_ring* ring = nullptr;  // staging of the host-buffer entry points (zk_host.hip)

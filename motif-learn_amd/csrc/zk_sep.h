@@ -174,15 +174,6 @@ struct zk_sep_tables {
   double* d_psplit = nullptr;       // [P_2 P_4 .. P_12 | P_1 P_3 .. P_11] (zero beyond the kernel's n_max)
   int32_t* d_strip_rows = nullptr; // [K + 1] strip kernel (even K): per frame row n1 | n2 << 8, the column pairs of its two sweeps
   int tile_pitch = 0;
-  // fused maps: fold weights + [n_theta][2][kernel_nmax] cos / sin(m theta).  One device table per distinct
-  // (folds, m_unselect, theta) option set, kept for the life of the plan (a few KiB each, at most
-  // ZK_TRIG_CACHE of them): a repeated call uploads nothing and never synchronises, and a launch in flight
-  // never sees its table overwritten.
-  struct trig_entry {
-    std::vector<double> host;
-    double* dev = nullptr;
-  };
-  std::vector<trig_entry> trig_cache;
   // batch kernel, one unit list per element type ([0] float32: K % 4 == 0, K >= 16; [1] float64: K even, K >= 8)
   struct batch_tables {
     int run = 0;                      // granules per source run: 8 (float32, K == 32 or wide) or 4

@@ -74,8 +74,6 @@ void zk_sep_free(zk_plan* p) {
     if (b.d_units) (void)hipFree(b.d_units);
     if (b.d_row_starts) (void)hipFree(b.d_row_starts);
   }
-  for (auto& e : t->trig_cache)
-    if (e.dev) (void)hipFree(e.dev);
   if (t->d_pfull_alloc) (void)hipFree(t->d_pfull_alloc);
   for (auto& b : t->stream) {
     if (b.d_units) (void)hipFree(b.d_units);

@@ -20,7 +20,8 @@
 
 // Build groups: the kernel instances are spread over several translation units (Makefile) so that they
 // compile in parallel: group 0 = n_max kernels 4..12 (and every non-template entry point), 1 = 14 / 16,
-// 2 = 20 / 24 (class-pass kernels).  Group 0's launcher forwards to the others.
+// 2 = 20 / 24 (class-pass kernels), 3 = 28 .. 40 (moments from the matrix-core plain sum, zk_direct_patches.hip).
+// Group 0's launcher forwards to the others.
 #ifndef ZK_NMAX_GROUP
 #define ZK_NMAX_GROUP 0
 #endif
@@ -28,11 +29,14 @@
 #define ZK_GROUP_FN(name) name
 #elif ZK_NMAX_GROUP == 1
 #define ZK_GROUP_FN(name) name##_g1
-#else
+#elif ZK_NMAX_GROUP == 2
 #define ZK_GROUP_FN(name) name##_g2
+#else
+#define ZK_GROUP_FN(name) name##_g3
 #endif
 
 #define ZK_MAX_FOLDS 8
+#define ZK_MAPS_WROW 48  // doubles per fold-weight row of the device table (|m| 0 .. 40 used)
 #define ZK_TRIG_CACHE 8  // device tables kept per plan, one per distinct (folds, m_unselect, theta) option set
 // waves per SIMD the register allocator is asked to fit (launch bound)
 #ifndef ZK_MAPS_2W
@@ -44,7 +48,7 @@
 
 struct zk_maps_params {
   int n_folds;
-  int unselect_mask;   // bit am set: moments with |m| == am are dropped (bit 0 always set)
+  unsigned long long unselect_mask;   // bit am set: moments with |m| == am are dropped (bit 0 always set)
   int normalize;       // 1: p = 2, 0: p = None
   int n_theta;
   int plan_nmax;       // moments with n > plan_nmax are padding of the kernel set
@@ -135,7 +139,7 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
     norm2 += Em[m];
   }
   const double inv = prm.normalize ? 1.0 / norm2 : 1.0;  // 0/0 -> NaN exactly where NumPy gives NaN
-  // table layout: [ZK_MAX_FOLDS][ZK_SEP_ROW] fold weights by |m|, then per angle one compact row
+  // table layout: [ZK_MAX_FOLDS][ZK_MAPS_WROW] fold weights by |m|, then per angle one compact row
   // [cos(1 t) .. cos(NMAX t) | sin(1 t) .. sin(NMAX t)] -- 2 NMAX doubles, so the quarter grid of the default
   // 360 angles (91 rows, 14.6 KB at n_max 10) stays resident in the 16-KiB scalar cache
   const ZK_CONST double* wtab = zk_const(trig);
@@ -143,12 +147,12 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
     for (int f = 0; f < prm.n_folds; ++f) {
       double r = 0.0;
 #pragma unroll
-      for (int m = 0; m <= NMAX; ++m) r = __builtin_fma(wtab[f * ZK_SEP_ROW + m], Em[m], r);
+      for (int m = 0; m <= NMAX; ++m) r = __builtin_fma(wtab[f * ZK_MAPS_WROW + m], Em[m], r);
       if (live) rot_out[f * plane + pix_rot] = r * inv;
     }
   }
   if (mirror_out != nullptr) {
-    const ZK_CONST double* cs = wtab + ZK_MAX_FOLDS * ZK_SEP_ROW;
+    const ZK_CONST double* cs = wtab + ZK_MAX_FOLDS * ZK_MAPS_WROW;
     double best = -__builtin_inf();
     auto take = [&](double s) { best = s > best || s != s ? s : best; };  // NaN propagates like numpy.max
     if (prm.theta_sym == 2) {
@@ -479,6 +483,64 @@ int zk_maps_planes_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t 
 }
 #endif
 
+#if ZK_NMAX_GROUP == 3
+// n_max 25-40: as above with the moments of a band from the matrix-core plain sum (zk_direct_patches.hip)
+template <int NMAX>
+static int planes_band_g3(zk_plan* p, const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
+                          int64_t nb, int64_t W, int64_t b0, long long plane, hipStream_t s) {
+  int rc = zk_prof_begin(p, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(zk_maps_planes_kernel<NMAX>, dim3((unsigned)((nb * W + 255) / 256)), dim3(256), 0, s, p->d_scratch, d_trig,
+                     rot, ab, mirror, prm, (int)nb, (int)W, (int)b0, plane);
+  ZK_HIP(hipGetLastError());
+  return zk_prof_end(p, s);
+}
+
+int zk_maps_planes_large(zk_plan* p, int knm, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                      const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
+                      hipStream_t s) {
+  int64_t band = (int64_t)((size_t)1 << 30) / ((int64_t)p->n_poly * W * (int64_t)sizeof(double));
+  band = band < 8 ? 8 : (band > n_rows ? n_rows : band);
+  const size_t need = (size_t)p->n_poly * band * W * sizeof(double);
+  if (p->d_scratch_bytes < need) {
+    if (p->d_scratch) ZK_HIP(hipFree(p->d_scratch));
+    p->d_scratch = nullptr;
+    p->d_scratch_bytes = 0;
+    ZK_HIP(hipMalloc((void**)&p->d_scratch, need));
+    p->d_scratch_bytes = need;
+  }
+  const long long plane = zk_out_plane(p, n_rows, W);
+  for (int64_t b0 = 0; b0 < n_rows; b0 += band) {
+    const int64_t nb = n_rows - b0 < band ? n_rows - b0 : band;
+    const long long keep = p->out_plane;
+    p->out_plane = 0;  // the scratch matrix is compact
+    int rc = zk_launch_direct_frame(p, in, dtype, H, W, row0 + b0, nb, p->d_scratch, s);
+    p->out_plane = keep;
+    if (rc) return rc;
+    switch (knm) {
+      case 28: rc = planes_band_g3<28>(p, prm, d_trig, rot, ab, mirror, nb, W, b0, plane, s); break;
+      case 32: rc = planes_band_g3<32>(p, prm, d_trig, rot, ab, mirror, nb, W, b0, plane, s); break;
+      case 36: rc = planes_band_g3<36>(p, prm, d_trig, rot, ab, mirror, nb, W, b0, plane, s); break;
+      case 40: rc = planes_band_g3<40>(p, prm, d_trig, rot, ab, mirror, nb, W, b0, plane, s); break;
+      default: return zk_fail(ZK_E_BADARG, "no symmetry-map planes kernel for this n_max");
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int zk_maps_rows_large(zk_plan* p, int knm, const double* mom, int64_t n_rows, const zk_maps_params& prm,
+                             const double* d_trig, double* rot, double* ab, double* mirror, hipStream_t s) {
+  switch (knm) {
+    case 28: return launch_rows_one<28>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 32: return launch_rows_one<32>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 36: return launch_rows_one<36>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+    case 40: return launch_rows_one<40>(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
+  }
+  return zk_fail(ZK_E_BADARG, "no symmetry-map rows kernel for this n_max");
+}
+#endif
+
 #if ZK_NMAX_GROUP == 0
 int zk_maps_planes_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
                       const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
@@ -487,9 +549,29 @@ int zk_maps_dispatch_g1(zk_plan* p, const void* in, int dtype, int64_t H, int64_
                         const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
                         hipStream_t s);
 
-bool zk_sep_maps_available(const zk_plan* p, int dtype) {
-  return zk_sep_frame_available(p, dtype);  // n_max <= 16: fused in one kernel; 17-20: dense passes + planes kernel
+// n_max 25-40 (no polynomial tables: the reference basis is not the polynomial there): the moments of a row band come
+// from the matrix-core plain sum, the planes kernel of group 3 turns them into the maps
+static bool maps_on_direct(const zk_plan* p) {
+  const int n_max = zk_full_set_nmax(p);
+  return !p->sep && p->direct && n_max > 24 && n_max <= 40;
 }
+
+// the kernel instance a plan's maps run on
+static int maps_kernel_nmax(const zk_plan* p) {
+  if (p->sep) return p->sep->kernel_nmax;
+  return (zk_full_set_nmax(p) + 3) / 4 * 4;  // 28, 32, 36, 40
+}
+
+bool zk_sep_maps_available(const zk_plan* p, int dtype) {
+  // n_max <= 16: fused in one kernel; 17-24: dense passes + planes kernel; 25-40: matrix-core sums + planes kernel
+  return zk_sep_frame_available(p, dtype) || (maps_on_direct(p) && zk_direct_frame_available(p, dtype));
+}
+
+int zk_maps_planes_large(zk_plan* p, int knm, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows,
+                      const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
+                      hipStream_t s);
+int zk_maps_rows_large(zk_plan* p, int knm, const double* mom, int64_t n_rows, const zk_maps_params& prm,
+                             const double* d_trig, double* rot, double* ab, double* mirror, hipStream_t s);
 
 int zk_maps_rows_dispatch_g1(zk_plan* p, const double* mom, int64_t n_rows, const zk_maps_params& prm, const double* d_trig,
                              double* rot, double* ab, double* mirror, hipStream_t s);
@@ -504,7 +586,7 @@ static int maps_setup(zk_plan* p, const int32_t* folds, int n_folds, const int32
   if (p_norm != 0 && p_norm != 2) return zk_fail(ZK_E_BADARG, "p must be 2 or 0 (None)");
   if (rot && (!folds || n_folds == 0)) return zk_fail(ZK_E_BADARG, "rot output requested without folds");
   if (mirror && (!theta || n_theta <= 0)) return zk_fail(ZK_E_BADARG, "mirror output requested without theta");
-  const int knm = p->sep->kernel_nmax;
+  const int knm = maps_kernel_nmax(p);
   zk_maps_params prm = {};
   prm.n_folds = rot ? n_folds : 0;
   prm.normalize = p_norm == 2;
@@ -513,12 +595,12 @@ static int maps_setup(zk_plan* p, const int32_t* folds, int n_folds, const int32
   prm.unselect_mask = 0;
   for (int k = 0; k < n_unselect; ++k) {
     const int am = m_unselect[k] < 0 ? -m_unselect[k] : m_unselect[k];
-    if (am < 31) prm.unselect_mask |= 1 << am;
+    if (am < 64) prm.unselect_mask |= 1ull << am;
   }
   if (!(prm.unselect_mask & 1)) return zk_fail(ZK_E_BADARG, "m=0 must be included in m_unselect.");
   // device table: fold weights, then the trig rows (see the kernel)
   // (+ one spare row of zeros after the angles: the pipelined mirror scan prefetches one row ahead)
-  std::vector<double> tab((size_t)ZK_MAX_FOLDS * ZK_SEP_ROW + (size_t)(prm.n_theta > 0 ? n_theta + 1 : 0) * 2 * knm + 16, 0.0);
+  std::vector<double> tab((size_t)ZK_MAX_FOLDS * ZK_MAPS_WROW + (size_t)(prm.n_theta > 0 ? n_theta + 1 : 0) * 2 * knm + 16, 0.0);
   for (int f = 0; f < prm.n_folds; ++f) {
     const int fold = folds[f];
     if (fold <= 0) return zk_fail(ZK_E_BADARG, "folds must be positive");
@@ -529,8 +611,8 @@ static int maps_setup(zk_plan* p, const int32_t* folds, int n_folds, const int32
       if (am <= 1) w = 0.0;
       else if (am % fold == 0) w = 1.0;
       else w = fold > 1 ? -1.0 / (double)(fold - 1) : 0.0;
-      if (am < 31 && ((prm.unselect_mask >> am) & 1)) w = 0.0;  // dropped before the weights apply
-      tab[(size_t)f * ZK_SEP_ROW + am] = w;
+      if ((prm.unselect_mask >> am) & 1) w = 0.0;  // dropped before the weights apply
+      tab[(size_t)f * ZK_MAPS_WROW + am] = w;
     }
   }
   if (prm.n_theta > 0) {
@@ -538,12 +620,12 @@ static int maps_setup(zk_plan* p, const int32_t* folds, int n_folds, const int32
     for (int i = 0; i < n_theta && prm.theta_sym; ++i)
       prm.theta_sym = fabs(theta[i] - 2.0 * M_PI * (double)i / (double)n_theta) <= 1e-12;
     if (prm.theta_sym && n_theta % 8 == 0) prm.theta_sym = 2;  // eighth-grid scan
-    double* tr = tab.data() + (size_t)ZK_MAX_FOLDS * ZK_SEP_ROW;
+    double* tr = tab.data() + (size_t)ZK_MAX_FOLDS * ZK_MAPS_WROW;
     if (prm.theta_sym == 2) {
       // (cos theta_i, sin theta_i) for i = 0 .. n_theta/8, padded to a multiple of four rows with the last row
       const int last = n_theta / 8, rows4 = (last + 4) & ~3;
-      tab.resize((size_t)ZK_MAX_FOLDS * ZK_SEP_ROW + 2 * (size_t)rows4 + 16);
-      tr = tab.data() + (size_t)ZK_MAX_FOLDS * ZK_SEP_ROW;
+      tab.resize((size_t)ZK_MAX_FOLDS * ZK_MAPS_WROW + 2 * (size_t)rows4 + 16);
+      tr = tab.data() + (size_t)ZK_MAX_FOLDS * ZK_MAPS_WROW;
       for (int i = 0; i < rows4; ++i) {
         const int k = i < last ? i : last;
         tr[2 * i] = cos(theta[k]);
@@ -558,7 +640,7 @@ static int maps_setup(zk_plan* p, const int32_t* folds, int n_folds, const int32
         tr[(size_t)i * 2 * knm + knm + m - 1] = sin((double)m * theta[i]);
       }
   }
-  zk_sep_tables* t = p->sep;
+  zk_plan* t = p;
   const double* d_trig = nullptr;
   for (size_t k = 0; k < t->trig_cache.size() && !d_trig; ++k)
     if (t->trig_cache[k].host == tab) {
@@ -574,7 +656,7 @@ static int maps_setup(zk_plan* p, const int32_t* folds, int n_folds, const int32
       if (t->trig_cache.back().dev) (void)hipFree(t->trig_cache.back().dev);
       t->trig_cache.pop_back();
     }
-    zk_sep_tables::trig_entry e;
+    zk_plan::trig_entry e;
     ZK_HIP(hipMalloc((void**)&e.dev, tab.size() * sizeof(double)));
     hipError_t he = hipMemcpy(e.dev, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
     if (he != hipSuccess) {
@@ -594,12 +676,13 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
                        const int32_t* folds, int n_folds, const int32_t* m_unselect, int n_unselect, int p_norm,
                        const double* theta, int n_theta, double* rot, double* ab, double* mirror, hipStream_t s) {
   if (!zk_sep_maps_available(p, dtype))
-    return zk_fail(ZK_E_BADARG, "plan has no symmetry-map kernels (needs the separable tables: full Zernike set, n_max <= 24)");
+    return zk_fail(ZK_E_BADARG, "plan has no symmetry-map kernels (needs the full Zernike set, n_max <= 40)");
   zk_maps_params prm;
   const double* d_trig = nullptr;
   int rc = maps_setup(p, folds, n_folds, m_unselect, n_unselect, p_norm, theta, n_theta, rot, mirror, &prm, &d_trig);
   if (rc) return rc;
-  const int knm = p->sep->kernel_nmax;
+  const int knm = maps_kernel_nmax(p);
+  if (knm > 24) return zk_maps_planes_large(p, knm, in, dtype, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
   if (knm > 16) return zk_maps_planes_g2(p, in, dtype, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
   if (knm > 12) return zk_maps_dispatch_g1(p, in, dtype, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
   return zk_maps_dispatch(p, in, dtype, H, W, row0, n_rows, prm, d_trig, rot, ab, mirror, s);
@@ -609,13 +692,14 @@ int zk_launch_sep_maps(zk_plan* p, const void* in, int dtype, int64_t H, int64_t
 int zk_launch_maps_rows(zk_plan* p, const double* mom, int64_t n_rows, const int32_t* folds, int n_folds, const int32_t* m_unselect,
                         int n_unselect, int p_norm, const double* theta, int n_theta, double* rot, double* ab, double* mirror,
                         hipStream_t s) {
-  if (!p->sep || zk_full_set_nmax(p) < 0)
-    return zk_fail(ZK_E_BADARG, "plan has no symmetry-map kernels (needs the separable tables: full Zernike set, n_max <= 24)");
+  if ((!p->sep && !maps_on_direct(p)) || zk_full_set_nmax(p) < 0)
+    return zk_fail(ZK_E_BADARG, "plan has no symmetry-map kernels (needs the full Zernike set, n_max <= 40)");
   zk_maps_params prm;
   const double* d_trig = nullptr;
   int rc = maps_setup(p, folds, n_folds, m_unselect, n_unselect, p_norm, theta, n_theta, rot, mirror, &prm, &d_trig);
   if (rc) return rc;
-  const int knm = p->sep->kernel_nmax;
+  const int knm = maps_kernel_nmax(p);
+  if (knm > 24) return zk_maps_rows_large(p, knm, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
   if (knm > 16) return zk_maps_rows_dispatch_g2(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
   if (knm > 12) return zk_maps_rows_dispatch_g1(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);
   return zk_maps_rows_dispatch(p, mom, n_rows, prm, d_trig, rot, ab, mirror, s);

@@ -11,6 +11,7 @@ from mtflearn_amd import ZPs, _native, distributed as D
 from mtflearn_amd.synthetic import honeycomb_frame
 
 torch.cuda.set_device(0)
+theta = np.linspace(0, 2 * np.pi, 360, endpoint=False)
 f = torch.from_numpy(honeycomb_frame(2048, seed=0)).cuda()
 for n_max, K in ((24, 56), (28, 56), (32, 64), (36, 72)):
     with warnings.catch_warnings():
@@ -34,8 +35,17 @@ for n_max, K in ((24, 56), (28, 56), (32, 64), (36, 72)):
     D.frame_moments_device(plan, f, row0=384, n_rows=band, out=o2)
     torch.cuda.synchronize()
     k, ms_f = plan.profile_read()
+    # the symmetry maps of a 512-row band (moments from the dense kernel into scratch + the planes kernel)
+    mrows = 512
+    maps = D.frame_maps_device(plan, f, len(z.n) - sum(1 for m in z.m if m < 0), row0=256, n_rows=mrows, theta=theta)
+    torch.cuda.synchronize()
+    plan.profile_read()
+    D.frame_maps_device(plan, f, len(z.n) - sum(1 for m in z.m if m < 0), row0=256, n_rows=mrows, theta=theta)
+    torch.cuda.synchronize()
+    k_m, ms_m = plan.profile_read()
     plan.profile(False)
     kern = _native.PATH_NAMES[plan.best_path(0, _native.ZK_F32)]
     print(f"n_max {n_max:2d} K {K:3d} ({len(z.n)} moments)  batch [{kern}]: {p.shape[0] / ms_b / 1e3:8.2f} M patches/s   "
-          f"dense [{_native.PATH_NAMES[plan.best_path(1, _native.ZK_F32)]}]: {band * 2048 / ms_f / 1e3:8.2f} M positions/s", flush=True)
-    del out, o2, p
+          f"dense [{_native.PATH_NAMES[plan.best_path(1, _native.ZK_F32)]}]: {band * 2048 / ms_f / 1e3:8.2f} M positions/s   "
+          f"maps (rot 4 folds, |Z|, mirror 360): {mrows * 2048 / ms_m / 1e3:7.2f} M positions/s ({k_m} launches)", flush=True)
+    del out, o2, p, maps

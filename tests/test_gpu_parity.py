@@ -187,11 +187,16 @@ def test_symmetry_of_moment_rows(native, golden, zo):
 
     rng = np.random.default_rng(314)
     for n_max, size, n_rows in [(4, 16, 1), (6, 12, 257), (8, 32, 3000), (10, 32, 700), (12, 40, 513), (14, 32, 300),
-                                (16, 36, 255), (20, 44, 130), (23, 48, 70)]:
+                                (16, 36, 255), (20, 44, 130), (23, 48, 70),
+                                # above 24 (rows kernels 28 .. 40; |m| beyond 31 in m_unselect: the 64-bit mask)
+                                (25, 50, 65), (28, 56, 130), (31, 62, 64), (36, 72, 100), (40, 80, 67)]:
         zz = _zps(n_max, size)
+        if n_max > 24:
+            assert zz._device_plan().supports(native.OP_MAPS, native.ZK_F64)
         mom = rng.standard_normal((n_rows, len(zz.n))) * np.exp(rng.uniform(-3, 3, (n_rows, 1)))
         for kw in (dict(), dict(n_folds=[2, 5], m_unselect=(0, 2), p=None, theta=np.linspace(0, 2 * np.pi, 48, endpoint=False)),
-                   dict(n_folds=[1, 2, 3, 4, 5, 6, 7, 8], theta=np.linspace(0, np.pi, 37))):
+                   dict(n_folds=[1, 2, 3, 4, 5, 6, 7, 8], theta=np.linspace(0, np.pi, 37)),
+                   dict(n_folds=[3, 4], m_unselect=(0, 1, 24, 31, 33, 40))):
             got = zz.symmetry_of(mom, **kw)
             folds, unsel, pp = kw.get("n_folds", [2, 3, 4, 6]), kw.get("m_unselect", (0, 1)), kw.get("p", 2)
             rel_close(got["rot_maps"], zo.rot_maps(mom, zz.n, zz.m, list(folds), p=pp, m_unselect=unsel), rtol=1e-9)
@@ -286,14 +291,20 @@ def test_fused_symmetry_maps(native, golden, zo):
                                       (12, 40, (50, 70), np.float32), (14, 32, (40, 60), np.float32),
                                       (16, 36, (44, 48), np.float64),
                                       (18, 40, (45, 50), np.float32), (20, 44, (50, 47), np.float64),
-                                      (23, 48, (50, 52), np.float32)]:
+                                      (23, 48, (50, 52), np.float32),
+                                      # above 24: moments from the matrix-core plain sum + planes kernels 28 .. 40
+                                      (26, 52, (54, 70), np.float32), (32, 64, (70, 66), np.float64),
+                                      (36, 72, (80, 75), np.float32), (40, 80, (84, 90), np.float32)]:
         zz = _zps(n_max, size)
+        if n_max > 24:
+            assert zz._device_plan().supports(native.OP_MAPS, native.dtype_code(np.dtype(dtype)))
         frame = (rng.random(shape) + 0.1).astype(dtype)
         zm = zz.transform(frame)
         # independent of the product: the oracle's moments of this frame through the oracle's restatement of the
         # reference tail (_zmoments.py:300-316, 420-493)
         o_mom = zo.moments_frame_direct(frame, zz.polynomials)
-        floor = 3e-6 if n_max > 20 else 1e-7 if n_max > 16 else 1e-9 if n_max > 12 else 1e-10
+        # (17-24: the device sums the exact polynomial, the oracle the reference's rounded basis; above 24 both sum the basis)
+        floor = 1e-9 if n_max > 24 else 3e-6 if n_max > 20 else 1e-7 if n_max > 16 else 1e-9 if n_max > 12 else 1e-10
         for kw in (dict(), dict(n_folds=[2, 5], m_unselect=(0, 2), p=None, theta=np.linspace(0, 2 * np.pi, 48, endpoint=False))):
             got = zz.symmetry_maps(frame, **kw)
             folds, unsel, pp = kw.get("n_folds", [2, 3, 4, 6]), kw.get("m_unselect", (0, 1)), kw.get("p", 2)
@@ -325,18 +336,19 @@ def test_fused_symmetry_maps(native, golden, zo):
         z.symmetry_maps(img, m_unselect=(1,))
 
 
-def test_symmetry_maps_row_bands_above_n_max_16(native):
-    """n_max 17-20: the maps come from dense class passes into a scratch matrix (<= 1 GiB, i.e. row bands on a
-    wide frame) + the planes kernel.  A 4096-wide frame needs several bands; a 512-column crop needs one: the
-    maps must agree wherever the windows see the same pixels."""
-    z = _zps(17, 20)
+@pytest.mark.parametrize("n_max,size,height", [(17, 20, 400), (28, 56, 150)])
+def test_symmetry_maps_row_bands_above_n_max_16(native, n_max, size, height):
+    """n_max 17-24: the maps come from dense class passes into a scratch matrix (<= 1 GiB, i.e. row bands on a
+    wide frame) + the planes kernel; 25-40 the same with the moments from the matrix-core plain sum.  A 4096-wide frame
+    needs several bands; a 512-column crop needs one: the maps must agree wherever the windows see the same pixels."""
+    z = _zps(n_max, size)
     assert z._device_plan().supports(native.OP_MAPS, native.ZK_F32)
     rng = np.random.default_rng(21)
-    frame = (rng.random((400, 4096)) + 0.2).astype(np.float32)
+    frame = (rng.random((height, 4096)) + 0.2).astype(np.float32)
     wide = z.symmetry_maps(frame)
     crop = z.symmetry_maps(np.ascontiguousarray(frame[:, 1000:1512]))
     for key in ("rot_maps", "abs", "mirror_map"):
-        a, b = wide[key][..., 1020:1492], crop[key][..., 20:492]
+        a, b = wide[key][..., 1000 + size:1512 - size], crop[key][..., size:512 - size]
         assert a.shape == b.shape
         rel_close(a, b, rtol=1e-10, atol_scale=1e-12)
 
