@@ -93,7 +93,8 @@ void zk_plan_destroy(zk_plan* plan);
 /* Introspection: 1 if `path` (ZK_PATH_*) is available for `mode` (0 patches, 1 frame) and `dtype`. */
 int zk_plan_has_path(const zk_plan* plan, int mode, int dtype, int path);
 /* 1 if the plan has the single-kernel form of zk_transform_points (ZK_OP_POINTS: full Zernike set, n_max <= 16) /
- * the kernels behind zk_frame_maps (ZK_OP_MAPS: full Zernike set, n_max <= 24; fused in one kernel up to 16)
+ * the kernels behind zk_frame_maps (ZK_OP_MAPS: full Zernike set, n_max <= 40; fused in one kernel up to 16, moments into a
+ * scratch matrix + a planes kernel above)
  * for `dtype`.  (No reference counterpart: the reference composes these from ZPs.transform.) */
 #define ZK_OP_POINTS 1
 #define ZK_OP_MAPS   2
@@ -186,7 +187,7 @@ int zk_frame_maps_dev(zk_plan* plan, const void* image_dev, int dtype, int64_t h
  * _zmoments.py:300-316, 420-493), e.g. the moments at key points:
  *   moments (N, n_poly) row-major ->  rot (N, n_folds), abs (N, N_c), mirror (N)   (any output may be NULL)
  * zk_points_maps = zk_transform_points followed by that tail with the (N, n_poly) matrix never leaving the device
- * (the reference's notebook flow KeyPoints.extract_patches -> ZPs.transform -> rot_maps).  Full Zernike sets, n_max <= 24.
+ * (the reference's notebook flow KeyPoints.extract_patches -> ZPs.transform -> rot_maps).  Full Zernike sets, n_max <= 40.
  */
 int zk_moment_maps(zk_plan* plan, const double* moments_host, int64_t n_rows, const int32_t* folds, int n_folds,
                    const int32_t* m_unselect, int n_unselect, int p_norm, const double* theta, int n_theta,
