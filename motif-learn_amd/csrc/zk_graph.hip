@@ -77,9 +77,12 @@ __global__ __launch_bounds__(64 * WAVES) void knn_kernel(const double* __restric
   for (int p = 0; p < K; ++p) bd[p] = std::numeric_limits<double>::infinity(), bi[p] = -1;
   double worst = std::numeric_limits<double>::infinity();
   auto insert = [&](double cd, long long ci) {
+    // (the test uses the NEW value at every position, not the entry being pushed down: an entry displaced from a run of equal
+    //  distances must keep moving, or it would be overtaken by its equals and ties would lose their index order)
+    const double nd = cd;
 #pragma unroll
     for (int p = 0; p < K; ++p) {
-      const bool lt = cd < bd[p];
+      const bool lt = nd < bd[p];
       const double td = bd[p];
       const long long ti = bi[p];
       bd[p] = lt ? cd : td;
@@ -143,6 +146,223 @@ __global__ __launch_bounds__(64 * WAVES) void knn_kernel(const double* __restric
   }
 }
 
+// ---- k <= 16, D <= 96: the N x N scalar products as a GEMM on the matrix cores (round 3) ---------------------------------------
+// The search is 2 N^2 D flop of  Z Z^T  followed by a top-k per row; knn_kernel above does it with one query per lane and the
+// candidates as scalar operands (0.24 of the FP64 peak: a 36-MB scalar stream).  Here, v_mfma_f64_16x16x4_f64 with
+//   A = 16 candidates x 4 features,  B = 4 features x 16 queries,  D[candidate kr + 4 q][query li] in lane (li = lane & 15, kr = lane >> 4):
+// a lane sees, for ITS query li, the four candidates kr + 4 q of every block of 16 -- so every query is followed by four lanes.
+// Both operands come from ONE blocked copy of the unit rows,
+//   Zb[block of 16 rows][step of 4 features][lane] = z_{16 block + (lane & 15)}[4 step + (lane >> 4)],
+// i.e. the 512 bytes an MFMA wants are contiguous: queries are read once into registers (QB blocks of 16 per wave), candidates
+// are streamed by the LDS-DMA engine in stages of 64 rows shared by the four waves (64 QB queries per workgroup), double-
+// buffered, one barrier a stage.  Selection: all four lanes of a query keep the SAME sorted list; a value that beats the list's
+// k-th entry (a wave-wide ballot, rare after the first few hundred candidates) is handed to the four lanes by a lane shuffle
+// and inserted by all of them, block values in index order -- so the threshold is the exact k-th best so far and ties keep the
+// smaller index first.
+// Measured, 100 000 x 45, k = 10 (kernel time under rocprofv3): scalar-operand kernel 46 ms -> 21.7 ms = 0.56 of the FP64 peak
+// counting the 48 padded features (200 000 rows: 74 ms = 0.66; 400 000: 0.70).  Where the rest goes: with the selection off
+// 19.4 ms; without barriers, DMA and LDS reads as well 17.5 ms -- chains of 12 dependent MFMAs at three waves per SIMD and
+// 6.1 workgroups per CU (seven on some) do not go faster; tools/micro_mfma64_occ.hip has the chip's own limits (one
+// accumulator chain per wave: 57 / 68 / 70 TFLOP/s at 1 / 2 / 4 waves per SIMD; alternating chains are SLOWER).
+// Versions on the way: a list per lane over its quarter of the candidates, merged at the end (thresholds = the k-th best of
+// a quarter let four times as many values into the insertion code), two query blocks per wave with alternating accumulator
+// chains (782 workgroups for 256 CUs: four on some, three on most) -- both 27-28 ms.
+typedef double zk_v4d __attribute__((ext_vector_type(4)));
+#define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// unit rows in the blocked layout, `steps` = ceil(D / 4) feature steps, rows padded with zeros to `Np` (a multiple of 64)
+__global__ __launch_bounds__(256) void unit_rows_blocked_kernel(const double* __restrict__ X, long long N, int D, long long Np, int steps,
+                                                                double* __restrict__ Zb) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= Np) return;
+  double* out = Zb + (r >> 4) * steps * 64 + (r & 15);
+  double mean = 0.0, inv = 0.0;
+  const double* x = X + r * D;
+  if (r < N) {
+    double s = 0.0;
+    for (int f = 0; f < D; ++f) s += x[f];
+    mean = s / D;
+    double q = 0.0;
+    for (int f = 0; f < D; ++f) {
+      const double v = x[f] - mean;
+      q += v * v;
+    }
+    inv = q > 0.0 ? 1.0 / sqrt(q) : 0.0;
+  }
+  for (int f = 0; f < 4 * steps; ++f) out[(f >> 2) * 64 + (f & 3) * 16] = r < N && f < D ? (x[f] - mean) * inv : 0.0;
+}
+
+template <int K, int NS, int QB>
+__global__ __launch_bounds__(256, NS <= 12 && QB == 1 ? 3 : 2) void knn_mfma_kernel(const double* __restrict__ Zb, long long N, long long n_stages, int k,
+                                                          long long* __restrict__ ind, double* __restrict__ dist, int* __restrict__ part_ind,
+                                                          double* __restrict__ part_dist) {
+  constexpr int steps = NS;  // feature steps of the blocked copy (zero features up to 4 NS)
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // two stages of 64 candidates
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kr = lane >> 4;
+  constexpr int SB = NS <= 12 ? 4 : 2;  // candidate blocks per stage: 2 x 24 KiB of LDS at most, so two workgroups fit a CU
+  const long long n_blocks = n_stages * SB;
+  const long long qblock0 = ((long long)blockIdx.x * 4 + wave) * QB;
+  const int stage_doubles = SB * steps * 64;
+  const int n_int = (int)N;
+
+  double bq[QB][NS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bq[qb][s] = qblock0 + qb < n_blocks ? Zb[((qblock0 + qb) * steps + s) * 64 + lane] : 0.0;
+
+  double bd[QB][K], thr[QB];
+  int bi[QB][K];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    thr[qb] = std::numeric_limits<double>::infinity();
+#pragma unroll
+    for (int p = 0; p < K; ++p) bd[qb][p] = std::numeric_limits<double>::infinity(), bi[qb][p] = -1;
+  }
+
+  auto issue = [&](long long t, int buf) {
+    const char* src = (const char*)(Zb + t * stage_doubles) + lane * 16;
+    char* dst = (char*)(lds + buf * stage_doubles);
+    for (int c = wave; c < SB * steps / 2; c += 4)  // 1-KiB pieces of the stage
+      __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(src + c * 1024), ZK_LDS_PTR(dst + c * 1024), 16, 0, 0);
+  };
+
+  // blockIdx.y = the part of the candidate stages this workgroup scans (gridDim.y parts: more, smaller workgroups than
+  // query tiles alone give -- 100 000 rows are 782 tiles for 512 resident workgroups); the parts' lists are merged afterwards
+  const long long t_lo = n_stages * blockIdx.y / gridDim.y, t_hi = n_stages * (blockIdx.y + 1) / gridDim.y;
+  if (t_lo < t_hi) issue(t_lo, (int)(t_lo & 1));
+  double a[NS];
+  for (long long t = t_lo; t < t_hi; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage t have landed
+    __syncthreads();                                   // ... everybody's have, and nobody reads the other buffer any more
+    if (t + 1 < t_hi) issue(t + 1, (int)((t + 1) & 1));
+    const double* __restrict__ sb = lds + (t & 1) * stage_doubles + lane;
+    const bool tail = (t + 1) * (16 * SB) > N;  // the stage holds padding rows
+    // the A operand of step s of block cb + 1 is requested as soon as the MFMAs of step s of block cb have been issued (a
+    // lone wave on a SIMD would otherwise sit out an LDS round trip every four MFMAs)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s] = sb[s * 64];
+#pragma unroll
+    for (int cb = 0; cb < SB; ++cb) {
+      // one accumulator chain after the other: back-to-back MFMAs into the SAME accumulator run at 74 clocks each with two waves
+      // on the SIMD, two alternating chains at 78, four at 87 (tools/micro_mfma64_occ.hip); the last chain re-requests a[s]
+      zk_v4d acc[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        acc[qb] = zk_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          acc[qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bq[qb][s], acc[qb], 0, 0, 0);
+          if (qb == QB - 1 && cb + 1 < SB) {
+            a[s] = sb[((cb + 1) * steps + s) * 64];
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // the MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ... then the request for the next block's operand
+          }
+        }
+      }
+      const int cb0 = (int)(t * (16 * SB)) + cb * 16;  // candidate cb0 + g + 4 q is element q of lane group g (= kr of its lanes)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        double cd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cd[q] = 1.0 - acc[qb][q];
+        if (tail) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (cb0 + kr + 4 * q >= n_int) cd[q] = std::numeric_limits<double>::infinity();
+        }
+        const double best = __builtin_fmin(__builtin_fmin(cd[0], cd[1]), __builtin_fmin(cd[2], cd[3]));
+        if (__ballot(best < thr[qb])) {
+          // a value that beats its query's threshold goes to ALL FOUR lanes of the query, in index order (q outer, lane group
+          // inner), so the four lists stay equal and strict comparisons keep ties in index order.  Run-time loops: one copy
+          // of the insertion chain per query block keeps the loop body inside the instruction cache.
+#pragma nounroll
+          for (int q = 0; q < 4; ++q) {
+            const double cq = q == 0 ? cd[0] : q == 1 ? cd[1] : q == 2 ? cd[2] : cd[3];
+            unsigned long long hit = __ballot(cq < thr[qb]);
+            while (hit) {
+              const int g = __builtin_ctzll(hit) >> 4;  // the first lane group with a hit
+              hit &= ~(0xffffull << (16 * g));
+              const double nd = __shfl(cq, li + 16 * g, 64);
+              double vd = nd;
+              int vi = cb0 + g + 4 * q;
+#pragma unroll
+              for (int p = 0; p < K; ++p) {
+                const bool lt = nd < bd[qb][p];  // the new value, not the entry being pushed down (see knn_kernel)
+                const double td = bd[qb][p];
+                const int ti = bi[qb][p];
+                bd[qb][p] = lt ? vd : td;
+                bi[qb][p] = lt ? vi : ti;
+                vd = lt ? td : vd;
+                vi = lt ? ti : vi;
+              }
+              double w = bd[qb][K - 1];
+#pragma unroll
+              for (int p = 0; p < K - 1; ++p)
+                if (p == k - 1) w = bd[qb][p];
+              thr[qb] = w;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // the four lanes of a query hold the same list; lane group 0 writes it (one part: the result; else this part's list)
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const long long qrow = (qblock0 + qb) * 16 + li;
+    if (kr == 0 && qrow < N) {
+      if (gridDim.y == 1) {
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+          if (p < k) {
+            ind[qrow * k + p] = bi[qb][p];
+            dist[qrow * k + p] = bd[qb][p];
+          }
+      } else {
+        const long long o = ((long long)blockIdx.y * N + qrow) * k;
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+          if (p < k) {
+            part_ind[o + p] = bi[qb][p];
+            part_dist[o + p] = bd[qb][p];
+          }
+      }
+    }
+  }
+}
+
+// the k best of a query from the sorted lists of its `parts` candidate ranges (ascending ranges: on equal distances the lower
+// part, i.e. the smaller index, goes first); one thread per query
+__global__ __launch_bounds__(256) void knn_merge_kernel(const int* __restrict__ part_ind, const double* __restrict__ part_dist, long long N, int k,
+                                                        int parts, long long* __restrict__ ind, double* __restrict__ dist) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= N) return;
+  int head[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) head[c] = 0;
+  for (int p = 0; p < k; ++p) {
+    double best = std::numeric_limits<double>::infinity();
+    int from = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < parts && head[c] < k) {
+        const double v = part_dist[((long long)c * N + q) * k + head[c]];
+        if (v < best) best = v, from = c;
+      }
+    int h = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c == from) h = head[c]++;
+    ind[q * k + p] = part_ind[((long long)from * N + q) * k + h];
+    dist[q * k + p] = best;
+  }
+}
+
 // calculate_asymmetric_Pij (reference force_relaxed.py:17-52), one thread per row of the (N, k) neighbour distances
 __global__ __launch_bounds__(256) void affinity_kernel(const double* __restrict__ dist, long long N, int k, int local_connectivity,
                                                        double target, double* __restrict__ P) {
@@ -201,12 +421,24 @@ extern "C" int zk_rows_knn_correlation(zk_rows* m, int k, int local_connectivity
   const long long Np = (N + 7) & ~7LL;
   double *Z = nullptr, *Zt = nullptr, *d_dist = nullptr, *d_P = nullptr;
   long long* d_ind = nullptr;
+  void* part_bufs[2] = {nullptr, nullptr};
   auto cleanup = [&]() {
-    for (void* p : {(void*)Z, (void*)Zt, (void*)d_dist, (void*)d_P, (void*)d_ind})
+    for (void* p : {(void*)Z, (void*)Zt, (void*)d_dist, (void*)d_P, (void*)d_ind, part_bufs[0], part_bufs[1]})
       if (p) (void)hipFree(p);
   };
-  hipError_t e = hipMalloc((void**)&Z, (size_t)N * D * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&Zt, (size_t)Np * D * sizeof(double) + 256);
+  // k <= 16 and D <= 96: the matrix-core kernel on the blocked copy (ZK_KNN_SCALAR=1 keeps the scalar-operand kernel for A/B)
+  const char* force_scalar = getenv("ZK_KNN_SCALAR");
+  const bool mfma = k <= 16 && D <= 96 && N < (1LL << 31) - 64 && !(force_scalar && force_scalar[0] == '1');
+  // feature steps of the blocked copy: the kernel instance that holds D (zero features beyond it)
+  const int steps = D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : (D + 15) / 16 * 4;
+  const long long Np64 = (N + 63) & ~63LL;
+  hipError_t e = hipSuccess;
+  if (mfma)
+    e = hipMalloc((void**)&Z, (size_t)Np64 * steps * 4 * sizeof(double));
+  else {
+    e = hipMalloc((void**)&Z, (size_t)N * D * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&Zt, (size_t)Np * D * sizeof(double) + 256);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&d_dist, (size_t)N * k * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&d_ind, (size_t)N * k * sizeof(long long));
   if (e == hipSuccess && P_out) e = hipMalloc((void**)&d_P, (size_t)N * k * sizeof(double));
@@ -214,15 +446,73 @@ extern "C" int zk_rows_knn_correlation(zk_rows* m, int k, int local_connectivity
     cleanup();
     return zk_hip_fail(e, "hipMalloc(kNN buffers)");
   }
-  hipLaunchKernelGGL(unit_rows_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, s, zk_rows_data(m), (long long)N, D, Np, Z, Zt);
-  const size_t lds = (size_t)64 * D * sizeof(double);
-  const unsigned grid = (unsigned)((N + 63) / 64);
-  if (k <= 16)
-    hipLaunchKernelGGL((knn_kernel<16, 4>), dim3(grid), dim3(256), lds + (size_t)16 * 64 * 16, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
-  else if (k <= 32)
-    hipLaunchKernelGGL((knn_kernel<32, 1>), dim3(grid), dim3(64), lds, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
-  else
-    hipLaunchKernelGGL((knn_kernel<64, 1>), dim3(grid), dim3(64), lds, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
+  if (mfma) {
+    hipLaunchKernelGGL(unit_rows_blocked_kernel, dim3((unsigned)((Np64 + 255) / 256)), dim3(256), 0, s, zk_rows_data(m), (long long)N, D, Np64,
+                       steps, Z);
+    const int sb = steps <= 12 ? 4 : 2;  // candidate blocks per stage (the kernel's SB)
+    const size_t stage = (size_t)sb * steps * 64 * sizeof(double);
+    const size_t lds = 2 * stage;
+    const unsigned tiles1 = (unsigned)((N + 63) / 64);
+    const long long n_stages = Np64 / (16 * sb);
+    // One query block of 16 per wave, 64 queries per workgroup (QB = 1): 100 000 rows are 1 563 workgroups, 6.1 per CU -- with
+    // two blocks per wave (782 workgroups, 3.05 per CU, four on some) the busiest CUs set the time: 27 ms against 22.  Three
+    // workgroups fit a CU.  Small matrices are cut further, into parts of the candidate range (each part pays the fill-up of
+    // its lists again -- 100 000 x 45 in 1 / 2 / 4 / 8 / 16 parts: 28 / 27 / 29 / 32 / 38 ms -- so only up to one round of
+    // resident workgroups)
+    const unsigned tiles = tiles1;
+    int parts = (int)(3u * 256u / tiles);
+    if (const char* pe = getenv("ZK_KNN_PARTS")) parts = atoi(pe);
+    if (parts > n_stages / 16) parts = (int)(n_stages / 16);
+    parts = parts < 1 ? 1 : parts > 16 ? 16 : parts;
+    int* d_pind = nullptr;
+    double* d_pdist = nullptr;
+    if (parts > 1) {
+      e = hipMalloc((void**)&d_pind, (size_t)parts * N * k * sizeof(int));
+      if (e == hipSuccess) e = hipMalloc((void**)&d_pdist, (size_t)parts * N * k * sizeof(double));
+      if (e != hipSuccess) {
+        if (d_pind) (void)hipFree(d_pind);
+        cleanup();
+        return zk_hip_fail(e, "hipMalloc(kNN part lists)");
+      }
+    }
+    const dim3 grid1(tiles1, parts);
+    // (lists of 10 entries for k <= 10, ForceGraph8's default: a shorter insertion chain)
+#define ZK_KNN_CASE(NS)                                                                                                                  \
+  case NS:                                                                                                                              \
+    if (k <= 10)                                                                                                                        \
+      hipLaunchKernelGGL((knn_mfma_kernel<10, NS, 1>), grid1, dim3(256), lds, s, Z, (long long)N, n_stages, k, d_ind, d_dist,           \
+                         d_pind, d_pdist);                                                                                              \
+    else                                                                                                                                \
+      hipLaunchKernelGGL((knn_mfma_kernel<16, NS, 1>), grid1, dim3(256), lds, s, Z, (long long)N, n_stages, k, d_ind, d_dist,           \
+                         d_pind, d_pdist);                                                                                              \
+    break;
+    switch (steps) {
+      ZK_KNN_CASE(2)
+      ZK_KNN_CASE(4)
+      ZK_KNN_CASE(8)
+      ZK_KNN_CASE(12)
+      ZK_KNN_CASE(16)
+      ZK_KNN_CASE(20)
+      ZK_KNN_CASE(24)
+    }
+#undef ZK_KNN_CASE
+    if (parts > 1) {
+      hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_pind, d_pdist, (long long)N, k, parts, d_ind, d_dist);
+      // (freed after the stream has drained: cleanup() below runs after hipStreamSynchronize)
+      part_bufs[0] = d_pind;
+      part_bufs[1] = d_pdist;
+    }
+  } else {
+    hipLaunchKernelGGL(unit_rows_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, s, zk_rows_data(m), (long long)N, D, Np, Z, Zt);
+    const size_t lds = (size_t)64 * D * sizeof(double);
+    const unsigned grid = (unsigned)((N + 63) / 64);
+    if (k <= 16)
+      hipLaunchKernelGGL((knn_kernel<16, 4>), dim3(grid), dim3(256), lds + (size_t)16 * 64 * 16, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
+    else if (k <= 32)
+      hipLaunchKernelGGL((knn_kernel<32, 1>), dim3(grid), dim3(64), lds, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
+    else
+      hipLaunchKernelGGL((knn_kernel<64, 1>), dim3(grid), dim3(64), lds, s, Z, Zt, (long long)N, D, Np, k, d_ind, d_dist);
+  }
   if (P_out)
     hipLaunchKernelGGL(affinity_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_dist, (long long)N, k, local_connectivity,
                        std::log2(perplexity), d_P);

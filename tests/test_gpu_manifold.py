@@ -49,6 +49,40 @@ def test_neighbours_and_affinities(mo):
         compute_graph(X, 3, "euclidean")
 
 
+def test_matrix_core_search_against_the_scalar_kernel_and_sklearn(monkeypatch):
+    """k <= 16, D <= 96 runs as a GEMM on the matrix cores (knn_mfma_kernel): ragged row counts around the 16 / 64 / 128-row
+    blocking, 1-24 feature steps, exact ties (duplicated rows keep the smaller index first, as the scalar-operand kernel does)."""
+    from sklearn.neighbors import NearestNeighbors
+    from mtflearn_amd.clustering import DeviceRows
+    from mtflearn_amd.manifold import _knn_affinities
+    rng = np.random.default_rng(11)
+    cases = [(16, 4, 16), (17, 45, 3), (63, 45, 10), (65, 45, 16), (129, 28, 3), (257, 5, 1), (777, 91, 16), (1000, 96, 12),
+             (5000, 45, 16), (4097, 66, 10)]
+    for n, d, k in cases:
+        X = rng.standard_normal((n, d)) + rng.standard_normal(d)
+        d_ref, i_ref = NearestNeighbors(n_neighbors=k, metric="correlation").fit(X).kneighbors(X, n_neighbors=k)
+        with DeviceRows(X) as rows:
+            dist, ind, _ = _knn_affinities(rows, k, min(1, k - 1), k)
+        np.testing.assert_array_equal(ind, i_ref, err_msg=str((n, d, k)))
+        np.testing.assert_allclose(dist, d_ref, rtol=0, atol=1e-13)
+    # exact ties: every row three times, shuffled
+    base = rng.standard_normal((700, 45))
+    X = np.concatenate([base, base, base])[rng.permutation(2100)]
+    with DeviceRows(X) as rows:
+        d_m, i_m, _ = _knn_affinities(rows, 9, 1, 9)
+        monkeypatch.setenv("ZK_KNN_SCALAR", "1")
+        d_s, i_s, _ = _knn_affinities(rows, 9, 1, 9)
+        monkeypatch.delenv("ZK_KNN_SCALAR")
+        monkeypatch.setenv("ZK_KNN_PARTS", "2")          # the candidate range in two parts, merged by (distance, part)
+        d_p, i_p, _ = _knn_affinities(rows, 9, 1, 9)
+        monkeypatch.delenv("ZK_KNN_PARTS")
+    np.testing.assert_array_equal(i_m, i_s)
+    np.testing.assert_array_equal(i_p, i_s)
+    np.testing.assert_array_equal(d_p, d_s)
+    np.testing.assert_allclose(d_m, d_s, rtol=0, atol=1e-13)
+    assert (np.sort(i_m[:, :3], axis=1) == np.sort(np.stack([np.flatnonzero((X == x).all(1)) for x in X]), axis=1)).all()
+
+
 def test_force_graph8_end_to_end(mo):
     """Same graph (to rounding), same PCA start, same random state -> the sequential optimiser, which is bit-identical to the
     restatement given identical inputs (tests/test_manifold_cpu.py), lands on the same layout up to the amplification of the
