@@ -113,6 +113,15 @@ struct tile_pipe {
   }
 };
 
+// v of the lane a DPP control names (quad_perm / row mirrors: lanes of the same row of 16), for a double
+template <int CTRL>
+__device__ __forceinline__ double zk_dpp_f64(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -550,6 +559,134 @@ __global__ __launch_bounds__(64 * ZK_EWAVES) void estep_kernel(const double* __r
   }
 }
 
+// ---- E step on the matrix cores (round 3): y = x P_c as  (16 rows x D) . (D x 16-column blocks of the factor) -------------------
+// Round 2's attempt above lost because every lane fetched its own element of the factor from global memory.  Here the factors
+// of ALL components sit in LDS for the life of the workgroup, already in the MFMA operand order --
+//   tabP[c][bj][s][lane] = P_c[4 s + (lane >> 4)][16 bj + (lane & 15)],  s < 4 (bj + 1)   (upper triangle; zeros elsewhere)
+// (24 steps x 512 B = 12 KiB per component at D <= 48) -- so a B operand is one conflict-free ds_read_b64, and the eight waves
+// of a workgroup (two per SIMD, one workgroup per CU) stream their OWN 16-row blocks of the matrix: the block is DMA'd into a
+// wave-private 16 x D buffer, its A operands A[i][k] = x_{row i}[4 s + k] are pulled into registers once (all components and
+// column blocks reuse them), and the DMA of the wave's next block is issued straight away -- no barrier after the table load.
+// Per (component, column block): one accumulator chain (initialised with -mu P, so the result is y), then sq += y^2; per
+// component a 16-lane row reduction (DPP) and four lanes park the four row sums in a wave-private table; the epilogue runs with
+// lane = (row, slot): slot s takes the exponentials of the components c = s (mod 4).
+// FULL: every piece of the upper triangle ('full' / 'tied' factors); else only the four diagonal pieces of a column block
+// ('diag' / 'spherical' factors: the host looks at the factors it was given).
+template <int NB, bool FULL>
+__global__ __launch_bounds__(512, 2) void estep_mfma_kernel(const double* __restrict__ X, long long N, int D, const double* __restrict__ tabP,
+                                                            const double* __restrict__ tabB /* [k][NB][16]: -mu P */,
+                                                            const double* __restrict__ cst, double dlog2pi, int k,
+                                                            double* __restrict__ resp, int32_t* __restrict__ labels,
+                                                            double* __restrict__ part) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  constexpr int NS = 4 * NB;                  // feature steps of a row block
+  constexpr int PSTEPS = 2 * NB * (NB + 1);   // operand pieces per component
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int li = lane & 15, kr = lane >> 4;
+  double* const ptab = lds;                                   // [k][PSTEPS][64]
+  double* const btab = ptab + (long long)k * PSTEPS * 64;     // [k][NB][16]
+  double* const mine = btab + k * NB * 16 + wave * (16 * D + 4 + 16 * 8);  // this wave's row block [16][D] (+ pad), then sq [8 slots][16]
+  double* const sqt = mine + 16 * D + 4;
+  {  // the factor table: one cooperative copy
+    const long long n = (long long)k * PSTEPS * 64 + k * NB * 16;
+    for (long long e = threadIdx.x; e < n; e += 512) lds[e] = e < (long long)k * PSTEPS * 64 ? tabP[e] : tabB[e - (long long)k * PSTEPS * 64];
+  }
+  const long long n_blocks = (N + 15) / 16, stride = (long long)gridDim.x * 8;
+  long long b = (long long)blockIdx.x * 8 + wave;
+  const int n_gran = 8 * D;  // 16-byte granules of a block
+  auto issue = [&](long long bb) {
+    if ((bb + 1) * 16 > N) return;  // the ragged last block is copied with ordinary loads
+    const char* src = (const char*)(X + bb * 16 * D);
+    for (int q = 0; q * 64 < n_gran; ++q) {
+      const int g = q * 64 + lane;
+      if (g < n_gran) __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(src + (long long)g * 16), ZK_LDS_PTR((char*)mine + q * 1024), 16, 0, 2);
+    }
+  };
+  if (b < n_blocks) issue(b);
+  __syncthreads();  // the table is in place (the only barrier)
+  const ZK_CONST double* cc = zk_const(cst);
+  double lse_sum = 0.0;
+  for (; b < n_blocks; b += stride) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((b + 1) * 16 > N) {
+      const long long base = b * 16 * D, total = N * D;
+      for (int e = lane; e < 16 * D; e += 64) mine[e] = base + e < total ? X[base + e] : 0.0;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    double a[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int f = 4 * s + kr;
+      a[s] = mine[li * D + (f < D ? f : 0)];
+      if (f >= D) a[s] = 0.0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the block is in registers: its buffer can take the next one
+    if (b + stride < n_blocks) issue(b + stride);
+    for (int c = 0; c < k; ++c) {
+      const double* __restrict__ pc = ptab + ((long long)c * PSTEPS) * 64 + lane;
+      double sq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int bj = 0; bj < NB; ++bj) {
+        const double nb = btab[(c * NB + bj) * 16 + li];
+        v4d acc = {nb, nb, nb, nb};
+        const double* __restrict__ pb = pc + (2 * bj * (bj + 1)) * 64;  // pieces of the column blocks before bj: 4 (1 + .. + bj)
+#pragma unroll
+        for (int s = FULL ? 0 : 4 * bj; s < 4 * (bj + 1); ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], pb[s * 64], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sq[q] = __builtin_fma(acc[q], acc[q], sq[q]);
+      }
+      // sum over the 16 columns a lane group holds (rows kr + 4 q): quad xor 1, xor 2, half-row mirror, row mirror
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sq[q] += zk_dpp_f64<0xB1>(sq[q]);
+        sq[q] += zk_dpp_f64<0x4E>(sq[q]);
+        sq[q] += zk_dpp_f64<0x141>(sq[q]);
+        sq[q] += zk_dpp_f64<0x140>(sq[q]);
+      }
+      if (li == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sqt[c * 16 + kr + 4 * q] = sq[q];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- epilogue: lane = (row li, slot kr) ---------------------------------------------------------------------------------
+    double best = -std::numeric_limits<double>::infinity();
+    int bl = 0;
+    for (int c = 0; c < k; ++c) {
+      const double v = (-0.5 * (dlog2pi + sqt[c * 16 + li]) + cc[2 * c]) + cc[2 * c + 1];
+      if (v > best) best = v, bl = c;
+    }
+    double ssum = 0.0;
+    for (int c = kr; c < k; c += 4) ssum += exp(((-0.5 * (dlog2pi + sqt[c * 16 + li]) + cc[2 * c]) + cc[2 * c + 1]) - best);
+    ssum += __shfl_xor(ssum, 16, 64);
+    ssum += __shfl_xor(ssum, 32, 64);
+    const double lse = log(ssum) + best;
+    const long long r = b * 16 + li;
+    if (r < N) {
+      if (kr == 0) {
+        lse_sum += lse;
+        if (labels) labels[r] = bl;
+      }
+      if (resp)
+        for (int c = kr; c < k; c += 4)
+          __builtin_nontemporal_store(exp(((-0.5 * (dlog2pi + sqt[c * 16 + li]) + cc[2 * c]) + cc[2 * c + 1]) - lse), resp + (long long)c * N + r);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // sqt is read before the next block's sums overwrite it
+  }
+  // one partial sum per workgroup (waves in order)
+  const double tot = wave_sum(lse_sum);
+  __syncthreads();
+  if (lane == 0) lds[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 8; ++w) t += lds[w];
+    part[blockIdx.x] = t;
+  }
+}
+
 // resp[c][r] = (labels[r] == c)
 __global__ __launch_bounds__(256) void onehot_kernel(const int32_t* __restrict__ labels, long long N, int k, double* __restrict__ resp) {
   const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -741,7 +878,10 @@ __global__ __launch_bounds__(256, 2) void wgram_mfma_kernel(const double* __rest
       for (int c = 0; c < KC; ++c) pw[c * TILE + lane] = r0 + lane < N ? (w ? w[(long long)c * N + r0 + lane] : 1.0) : 0.0;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    // operands of step s + 1 are read while the MFMAs of step s run (branch-free: the constant columns are selected afterwards)
+    // operands of step s + 1 are read while the MFMAs of step s run (branch-free: the constant columns are selected afterwards).
+    // (Round 3 also tried one accumulator chain per component -- the fast form of tools/micro_mfma64_occ.hip -- with the tile's 16
+    //  operand pairs kept in registers: 1.41 ms against 1.39 for six components; the weight products, not the chain order, are
+    //  what the MFMAs wait for here.)
     const double* ta = pa + kr * 16 + (lane & 15);
     const double* tz = pz + kr * 16 + (lane & 15);
     const double* wt = pw + kr;
@@ -1293,6 +1433,72 @@ extern "C" int zk_gmm_estep(zk_rows* m, const double* prec_chol, const double* m
     }
     C[2 * c] = log_det[c];
     C[2 * c + 1] = log_w[c];
+  }
+  // matrix-core form (D <= 48, k <= 8: the factors of all components fit the LDS of a CU beside the waves' row blocks)
+  static const bool no_mfma = getenv("ZK_ESTEP_VALU") != nullptr;  // A/B runs: the scalar-operand kernel
+  const int NB = (D + 15) / 16;
+  if (NB <= 3 && k <= 8 && D >= 2 && !no_mfma) {
+    const int psteps = 2 * NB * (NB + 1);
+    bool diag = true;  // only the diagonal pieces hold anything: 'diag' / 'spherical' factors
+    for (int c = 0; c < k && diag; ++c)
+      for (int i = 0; i < D && diag; ++i)
+        for (int j = i; j < D; ++j)
+          if (prec_chol[((size_t)c * D + i) * D + j] != 0.0 && i / 16 != j / 16) {
+            diag = false;
+            break;
+          }
+    h.assign((size_t)k * psteps * 64 + (size_t)k * NB * 16 + 2 * (size_t)k, 0.0);
+    double* TP = h.data();
+    double* TB = TP + (size_t)k * psteps * 64;
+    double* TC = TB + (size_t)k * NB * 16;
+    for (int c = 0; c < k; ++c) {
+      const double* pc = prec_chol + (size_t)c * D * D;
+      for (int bj = 0; bj < NB; ++bj)
+        for (int s = 0; s < 4 * (bj + 1); ++s)
+          for (int l = 0; l < 64; ++l) {
+            const int i = 4 * s + (l >> 4), j = 16 * bj + (l & 15);
+            TP[((size_t)c * psteps + 2 * bj * (bj + 1) + s) * 64 + l] = i < D && j < D && i <= j ? pc[(size_t)i * D + j] : 0.0;
+          }
+      for (int j = 0; j < D; ++j) {  // -(mu P)_j, the order of numpy.dot(mu, prec_chol)
+        double sj = 0.0;
+        for (int i = 0; i <= j; ++i) sj += means[(size_t)c * D + i] * pc[(size_t)i * D + j];
+        TB[(size_t)c * NB * 16 + j] = -sj;
+      }
+      TC[2 * c] = log_det[c];
+      TC[2 * c + 1] = log_w[c];
+    }
+    int rc = upload_tab(m, h);
+    h.clear();
+    if (rc) return rc;
+    const size_t lds = ((size_t)k * psteps * 64 + (size_t)k * NB * 16 + 8 * ((size_t)16 * D + 4 + 128)) * sizeof(double);
+    if ((rc = check_lds(lds))) return rc;
+    const long long n_blocks = (m->N + 15) / 16;
+    const int grid = (int)std::min<long long>((n_blocks + 7) / 8, (long long)m->n_cu);
+    if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * sizeof(double)))) return rc;
+    if (want_resp && (rc = ensure(&m->d_resp, &m->resp_bytes, (size_t)k * m->N * sizeof(double)))) return rc;
+    if (!m->d_labels) ZK_HIP(hipMalloc((void**)&m->d_labels, (size_t)m->N * sizeof(int32_t)));
+    const double* tab = (const double*)m->d_tab;
+    const double* d_tb = tab + (size_t)k * psteps * 64;
+    const double* d_tc = d_tb + (size_t)k * NB * 16;
+    if ((rc = prof_begin(m))) return rc;
+#define ZK_ESTEP_LAUNCH(NBV, FULLV)                                                                                                     \
+  {                                                                                                                                     \
+    if ((rc = allow_lds(estep_mfma_kernel<NBV, FULLV>, lds))) return rc;                                                                \
+    hipLaunchKernelGGL((estep_mfma_kernel<NBV, FULLV>), dim3(grid), dim3(512), lds, m->stream, m->X, (long long)m->N, D, tab, d_tb, d_tc, \
+                       (double)D * std::log(2.0 * M_PI), k, want_resp ? (double*)m->d_resp : nullptr, m->d_labels, (double*)m->d_part); \
+  }
+    if (NB == 1) {
+      if (diag) ZK_ESTEP_LAUNCH(1, false) else ZK_ESTEP_LAUNCH(1, true)
+    } else if (NB == 2) {
+      if (diag) ZK_ESTEP_LAUNCH(2, false) else ZK_ESTEP_LAUNCH(2, true)
+    } else {
+      if (diag) ZK_ESTEP_LAUNCH(3, false) else ZK_ESTEP_LAUNCH(3, true)
+    }
+#undef ZK_ESTEP_LAUNCH
+    ZK_HIP(hipGetLastError());
+    if ((rc = prof_end(m))) return rc;
+    if ((rc = reduce_to_host(m, grid, 1, lse_sum_out))) return rc;
+    return prof_read(m);
   }
   int rc = upload_tab(m, h);
   h.clear();

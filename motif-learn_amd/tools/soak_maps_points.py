@@ -2,7 +2,7 @@
 """Soak: seeded random plans; ZPs.symmetry_maps (fused / planes kernels) against the container's NumPy methods on the
 device moments, and ZPs.transform_at (key-point kernel / device gather) against the batch path on host-cut windows.
 
-  python motif-learn_amd/tools/soak_maps_points.py [seed] [iterations]
+  python motif-learn_amd/tools/soak_maps_points.py [seed] [iterations] [n_max below this bound, default 25]
 """
 import os, sys, warnings
 import numpy as np
@@ -26,7 +26,7 @@ def check(tag, got, ref, tol):
 
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 100):
     size = int(rng.integers(8, 73))
-    n_max = int(min(size, rng.integers(2, 25)))
+    n_max = int(min(size, rng.integers(2, int(sys.argv[3]) if len(sys.argv) > 3 else 25)))
     dtype = np.float32 if rng.random() < 0.6 else np.float64
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

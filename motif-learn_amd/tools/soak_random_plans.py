@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak: seeded random (size, n_max, dtype, shapes); every kernel family a plan offers against the generic kernel.
 
-  python motif-learn_amd/tools/soak_random_plans.py [seed] [iterations]
+  python motif-learn_amd/tools/soak_random_plans.py [seed] [iterations] [n_max below this bound, default 25; 41 reaches the
+  matrix-core plain sums of n_max 25-40]
 """
 import sys, numpy as np, warnings, os
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,8 +19,9 @@ def both(z, array, mode):
     plan.set_path(native.PATH_AUTO); return out
 rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 123)
 bad=0; n_cmp=0
+NMAX_BOUND=int(sys.argv[3]) if len(sys.argv)>3 else 25
 for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 300):
-    size=int(rng.integers(8,97)); n_max=int(min(size, rng.integers(0,25)))
+    size=int(rng.integers(8,97)); n_max=int(min(size, rng.integers(0,NMAX_BOUND)))
     dtype=np.float32 if rng.random()<0.6 else np.float64
     z=zps(n_max,size)
     p=(rng.random((int(rng.integers(1,400)),size,size))-0.4).astype(dtype)
@@ -33,5 +35,5 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 300):
                 err=np.abs(got-ref).max()/np.abs(ref).max()
                 if not err<=floor:
                     bad+=1; print("MISMATCH",size,n_max,dtype.__name__,mode,name,err,flush=True)
-    if it%50==49: print("iter",it+1,"comparisons",n_cmp,"bad",bad,flush=True)
+    if it%10==9: print("iter",it+1,"comparisons",n_cmp,"bad",bad,flush=True)
 print("done comparisons",n_cmp,"bad",bad)

@@ -235,6 +235,43 @@ def test_row_passes_on_edge_shapes():
             np.testing.assert_allclose(dev.project(mean, comp), host.project(mean, comp), rtol=1e-11, atol=1e-11)
 
 
+def test_mixture_e_step_on_the_matrix_cores():
+    """zk_gmm_estep for D <= 48 and k <= 8 runs as y = x P on the matrix cores (estep_mfma_kernel): the whole upper triangle for
+    'full' / 'tied' factors, the diagonal pieces only for 'diag' / 'spherical' ones; 1 to 3 column blocks, row counts around
+    the 16-row blocks of a wave and the 128 rows of a workgroup round; against the NumPy statement -- log-likelihood, labels and
+    (through the weighted moments) the responsibilities."""
+    from scipy import linalg
+    from test_clustering_sharded_cpu import HostRows
+    from mtflearn_amd.clustering import DeviceRows
+    rng = np.random.default_rng(5)
+    for n, d in [(1, 2), (15, 16), (16, 17), (17, 32), (127, 33), (128, 45), (129, 48), (1000, 45), (4099, 40), (70001, 45)]:
+        X = rng.standard_normal((n, d)) * (1 + rng.random(d)) + rng.standard_normal(d) * 2
+        host = HostRows(X)
+        with DeviceRows(X) as dev:
+            for k in (1, 4, 8):
+                if k > n:
+                    continue
+                for kind in ("full", "diag"):
+                    means = X[rng.choice(n, k, replace=False)] + 0.1 * rng.standard_normal((k, d))
+                    prec = np.zeros((k, d, d))
+                    for c in range(k):
+                        if kind == "full":
+                            a = rng.standard_normal((d, d)) * 0.3 + np.eye(d) * 2
+                            prec[c] = linalg.solve_triangular(linalg.cholesky(a @ a.T, lower=True), np.eye(d), lower=True).T
+                        else:
+                            prec[c] = np.diag(0.5 + rng.random(d))
+                    log_det = np.log(np.einsum("kii->ki", prec)).sum(axis=1)
+                    log_w = np.log(rng.dirichlet(np.ones(k) * 5))
+                    lse_d, lse_h = dev.estep(prec, means, log_det, log_w), host.estep(prec, means, log_det, log_w)
+                    assert abs(lse_d - lse_h) <= 1e-10 * max(1.0, abs(lse_h)), (n, d, k, kind)
+                    agree = np.mean(dev.labels() == host.labels())
+                    assert agree == 1.0 or (agree > 0.999 and n > 500), (n, d, k, kind, agree)
+                    shift = X.mean(axis=0)
+                    for c in range(k):
+                        g_h = host.moments(c, shift)
+                        np.testing.assert_allclose(dev.moments(c, shift), g_h, rtol=1e-10, atol=1e-10 * np.abs(g_h).max())
+
+
 def test_sharded_control_flow_on_the_device_passes():
     """The sharded code path (``comm=``) driving real device passes: a two-rank communicator whose other rank holds no rows and
     contributes zeros to every sum -- labels, centres, mixture labels and PCA scores must equal the single-block run."""
