@@ -392,6 +392,15 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
   }
 }
 
+// Tried in round 3 and not kept: a PERSISTENT form (two workgroups per CU walking the tiles, the next tile's raw rows copied by
+// the LDS-DMA engine under the current tile's arithmetic, widened to float64 at the tile switch; the DMA wait placed before the
+// tile's stores, bare s_barrier instead of __syncthreads() -- whose fence waits for the 90 outstanding stores per lane -- and
+// the DMA issued from inline asm so that the compiler does not put vmcnt(0) in front of the LDS reads).  Per 2048^2, one tile
+// per workgroup -> persistent: (32, 4) 0.35 -> 0.53 ms, (32, 8) 0.84 -> 0.95, (32, 12) 1.64 -> 1.70; the same kernel launched
+// with one workgroup per tile (no persistence, DMA staging only) is level with the one-tile form (0.88).  What the hardware's
+// own dispatch gives -- workgroups of a CU drifting out of phase, so that one's staging falls under the other's arithmetic,
+// and tiles handed to whichever CU is free -- is worth more than the hidden round trips; two equal workgroups that start
+// together stay in lock step and stage together.
 template <int NMAX, typename T, int QM>
 int launch_strip2(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out, hipStream_t s) {
   const zk_sep_tables* t = p->sep;
