@@ -581,8 +581,42 @@ def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4, cpu_sample=
             kernel_ms += rows.last_kernel_ms() / 5
         s_pass = worst((time.perf_counter() - t0) / 5)
         kernel_ms = worst(kernel_ms)
+        # the two passes of a Gaussian-mixture EM iteration (gmm_lbs), k = 6 full covariances, on the same resident block: kernels
+        # on the matrix cores; local passes only (no collective), every rank its own block
+        kg = 6
+        rng = np.random.default_rng(0)
+        prec = np.stack([np.triu(rng.standard_normal((n_poly, n_poly)) * 0.05, 1) + np.eye(n_poly) * (1.0 + 0.1 * c) for c in range(kg)])
+        means_g = rng.standard_normal((kg, n_poly)) * 0.01
+        log_det = np.log(np.einsum("kii->ki", prec)).sum(axis=1)
+        log_w = np.log(np.full(kg, 1.0 / kg))
+        rows.estep(prec, means_g, log_det, log_w)
+        e_ms = m_ms = 0.0
+        for _ in range(3):
+            rows.estep(prec, means_g, log_det, log_w)
+            e_ms += rows.last_kernel_ms() / 3
+            rows.moments(0, np.zeros(n_poly), count=kg)
+            m_ms += rows.last_kernel_ms() / 3
+        e_ms, m_ms = worst(e_ms), worst(m_ms)
+        rows.profile(False)
     finally:
         rows.close()
+    # correlation kNN of ForceGraph8.compute_graph on the first 100 000 moment vectors (its own resident copy)
+    knn = None
+    n_knn = min(100000, n_local)
+    if n_knn >= 1024:
+        from mtflearn_amd.manifold import _knn_affinities
+        with DeviceRows(mine[:n_knn].cpu().numpy()) as sub:
+            _knn_affinities(sub, 10, 1, 10)
+            t0 = time.perf_counter()
+            _knn_affinities(sub, 10, 1, 10)
+            s_knn = worst(time.perf_counter() - t0)
+        steps = 12 if n_poly <= 48 else (n_poly + 15) // 16 * 4
+        knn = {"workload": f"zk_rows_knn_correlation: 10 nearest neighbours (correlation distance) + affinities of {n_knn} x {n_poly} rows, "
+                           "N^2 scalar products on the matrix cores with the top-k kept in the result lanes; wall clock of the C-ABI call "
+                           "(kernels + three result copies to the host)",
+               "ms": s_knn * 1e3,
+               "roofline": {"bound": "mfma-f64", "achieved": 2.0 * n_knn * n_knn * 4 * steps / s_knn / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                            "frac": 2.0 * n_knn * n_knn * 4 * steps / s_knn / 1e12 / 78.6}}
     sizes = np.bincount(whole, minlength=k).astype(np.int64)
     agree = True
     if comm is not None:
@@ -610,6 +644,20 @@ def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4, cpu_sample=
             "rows_per_s_end_to_end": n_total / (s_fit + s_gather), "cluster_sizes": sizes.tolist(), "ranks_agree": bool(agree),
             "label_bytes_gathered": 4 * n_total, "moment_bytes_not_gathered": 8 * n_poly * n_total}
     out["rows_x_iterations_per_s"] = n_total * n_iter / s_fit
+    # MFMA work of the mixture passes: E step k x (4 + 8 + .. + 4 NB) MFMAs of 2 048 flop per 16 rows; M step k x 6 blocks x 16 per 64 rows
+    nb = (n_poly + 15) // 16
+    if nb <= 3:
+        e_flop = kg * 2 * nb * (nb + 1) * 2048.0 / 16 * n_local
+        m_flop = kg * (nb * (nb + 1) // 2) * 16 * 2048.0 / 64 * n_local
+        out["mixture_em"] = {"workload": f"one EM iteration of gmm_lbs (k = {kg}, full covariances) on the rank's ({n_local}, {n_poly}) block: "
+                                         "E step (estep_mfma_kernel) and weighted second moments of all components (wgram_mfma_kernel)",
+                             "e_step_kernel_ms": e_ms, "m_step_kernel_ms": m_ms,
+                             "e_step_roofline": {"bound": "mfma-f64", "achieved": e_flop / (e_ms * 1e-3) / 1e12, "peak": 78.6,
+                                                 "unit": "TFLOP/s", "frac": e_flop / (e_ms * 1e-3) / 1e12 / 78.6},
+                             "m_step_roofline": {"bound": "mfma-f64", "achieved": m_flop / (m_ms * 1e-3) / 1e12, "peak": 78.6,
+                                                 "unit": "TFLOP/s", "frac": m_flop / (m_ms * 1e-3) / 1e12 / 78.6}}
+    if knn is not None:
+        out["knn_graph"] = knn
     if cpu is not None:
         out["cpu_baseline"] = cpu
         out["gpu_over_cpu"] = out["rows_x_iterations_per_s"] / cpu["value"]
