@@ -627,27 +627,32 @@ __global__ __launch_bounds__(512, 2) void estep_mfma_kernel(const double* __rest
     for (int c = 0; c < k; ++c) {
       const double* __restrict__ pc = ptab + ((long long)c * PSTEPS) * 64 + lane;
       double sq[4] = {0.0, 0.0, 0.0, 0.0};
+      v4d acc[NB];  // the NB chains back to back, their results read afterwards: one wait for the matrix pipe per component
 #pragma unroll
       for (int bj = 0; bj < NB; ++bj) {
         const double nb = btab[(c * NB + bj) * 16 + li];
-        v4d acc = {nb, nb, nb, nb};
+        acc[bj] = v4d{nb, nb, nb, nb};
         const double* __restrict__ pb = pc + (2 * bj * (bj + 1)) * 64;  // pieces of the column blocks before bj: 4 (1 + .. + bj)
 #pragma unroll
-        for (int s = FULL ? 0 : 4 * bj; s < 4 * (bj + 1); ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], pb[s * 64], acc, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sq[q] = __builtin_fma(acc[q], acc[q], sq[q]);
+        for (int s = FULL ? 0 : 4 * bj; s < 4 * (bj + 1); ++s) acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], pb[s * 64], acc[bj], 0, 0, 0);
       }
-      // sum over the 16 columns a lane group holds (rows kr + 4 q): quad xor 1, xor 2, half-row mirror, row mirror
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        sq[q] += zk_dpp_f64<0xB1>(sq[q]);
-        sq[q] += zk_dpp_f64<0x4E>(sq[q]);
-        sq[q] += zk_dpp_f64<0x141>(sq[q]);
-        sq[q] += zk_dpp_f64<0x140>(sq[q]);
-      }
-      if (li == 0) {
+      for (int bj = 0; bj < NB; ++bj)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sqt[c * 16 + kr + 4 * q] = sq[q];
+        for (int q = 0; q < 4; ++q) sq[q] = __builtin_fma(acc[bj][q], acc[bj][q], sq[q]);
+      // sum over the 16 columns a lane group holds (rows kr + 4 q), halving the number of values a lane carries at each of the
+      // first two steps: lane pairs (xor 1) split q {0, 1} | {2, 3}, pairs of pairs (xor 2) split again, then two row
+      // rotations (by 4 and 8 lanes) -- 5 additions instead of 16; lane li ends with the whole sum of q = 2 (li & 1) + ((li >> 1) & 1)
+      {
+        const bool hi1 = li & 1, hi2 = li & 2;
+        const double keep0 = hi1 ? sq[2] : sq[0], keep1 = hi1 ? sq[3] : sq[1];      // what this lane goes on with
+        const double give0 = hi1 ? sq[0] : sq[2], give1 = hi1 ? sq[1] : sq[3];      // what its partner goes on with
+        const double a0 = keep0 + zk_dpp_f64<0xB1>(give0), a1 = keep1 + zk_dpp_f64<0xB1>(give1);
+        const double keep = hi2 ? a1 : a0, give = hi2 ? a0 : a1;
+        double t = keep + zk_dpp_f64<0x4E>(give);
+        t += zk_dpp_f64<0x124>(t);  // row_ror:4 and :8 -- the other three quads' lanes with the same li & 3
+        t += zk_dpp_f64<0x128>(t);
+        if (li < 4) sqt[c * 16 + kr + 4 * (2 * (li & 1) + (li >> 1))] = t;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -658,20 +663,27 @@ __global__ __launch_bounds__(512, 2) void estep_mfma_kernel(const double* __rest
       const double v = (-0.5 * (dlog2pi + sqt[c * 16 + li]) + cc[2 * c]) + cc[2 * c + 1];
       if (v > best) best = v, bl = c;
     }
-    double ssum = 0.0;
-    for (int c = kr; c < k; c += 4) ssum += exp(((-0.5 * (dlog2pi + sqt[c * 16 + li]) + cc[2 * c]) + cc[2 * c + 1]) - best);
+    double ssum = 0.0, e0 = 0.0, e1 = 0.0;  // this slot's (at most two: k <= 8) exponentials
+    for (int c = kr, n = 0; c < k; c += 4, ++n) {
+      const double e = exp(((-0.5 * (dlog2pi + sqt[c * 16 + li]) + cc[2 * c]) + cc[2 * c + 1]) - best);
+      ssum += e;
+      if (n == 0) e0 = e;
+      else e1 = e;
+    }
     ssum += __shfl_xor(ssum, 16, 64);
     ssum += __shfl_xor(ssum, 32, 64);
     const double lse = log(ssum) + best;
+    const double inv = 1.0 / ssum;  // resp_c = exp(v_c - lse) = exp(v_c - best) / sum
     const long long r = b * 16 + li;
     if (r < N) {
       if (kr == 0) {
         lse_sum += lse;
         if (labels) labels[r] = bl;
       }
-      if (resp)
-        for (int c = kr; c < k; c += 4)
-          __builtin_nontemporal_store(exp(((-0.5 * (dlog2pi + sqt[c * 16 + li]) + cc[2 * c]) + cc[2 * c + 1]) - lse), resp + (long long)c * N + r);
+      if (resp) {
+        if (kr < k) __builtin_nontemporal_store(e0 * inv, resp + (long long)kr * N + r);
+        if (kr + 4 < k) __builtin_nontemporal_store(e1 * inv, resp + (long long)(kr + 4) * N + r);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // sqt is read before the next block's sums overwrite it
   }

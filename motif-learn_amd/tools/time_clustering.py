@@ -39,12 +39,17 @@ timed("seed pick + 4 searches", lambda: rows.seed_pick(1, np.array([1.0, 1e3, 1e
 c0 = centres - mean
 timed(f"lloyd pass, k = {k}, with sums", lambda: rows.lloyd(c0, True))
 timed(f"lloyd pass, k = {k}, labels only", lambda: rows.lloyd(c0, False))
-prec = np.tile(np.eye(D), (k, 1, 1)); logdet = np.zeros(k); logw = np.full(k, -np.log(k))
-timed(f"mixture E step, k = {k}", lambda: rows.estep(prec, centres, logdet, logw))
+# full upper-triangular factors ('full' / 'tied' covariances) and diagonal ones ('diag' / 'spherical': the matrix-core E step runs
+# only the diagonal pieces for those)
+prec = np.stack([np.triu(rng.standard_normal((D, D)) * 0.02, 1) + np.eye(D) for _ in range(k)])
+prec_diag = np.tile(np.eye(D), (k, 1, 1)); logdet = np.zeros(k); logw = np.full(k, -np.log(k))
+timed(f"mixture E step, k = {k}, full factors", lambda: rows.estep(prec, centres, logdet, logw))
+timed(f"mixture E step, k = {k}, diagonal", lambda: rows.estep(prec_diag, centres, logdet, logw))
 timed("mixture moments, one component", lambda: rows.moments(0, mean))
 timed(f"mixture moments, all {k} in one call", lambda: rows.moments(0, mean, count=k))
 rows.profile(True)
-for label, fn in (("E step", lambda: rows.estep(prec, centres, logdet, logw)), ("moments, one component", lambda: rows.moments(0, mean)),
+for label, fn in (("E step, full factors", lambda: rows.estep(prec, centres, logdet, logw)),
+                  ("E step, diagonal factors", lambda: rows.estep(prec_diag, centres, logdet, logw)), ("moments, one component", lambda: rows.moments(0, mean)),
                   (f"moments, all {k}", lambda: rows.moments(0, mean, count=k)), ("lloyd with sums", lambda: rows.lloyd(c0, True))):
     fn(); ms = []
     for _ in range(5):
