@@ -69,7 +69,7 @@ template <int NMAX, bool BY_ORDER = false, typename GET>
 __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& prm, const double* __restrict__ trig,
                                              bool live, long long plane, long long pix, double* __restrict__ rot_out,
                                              double* __restrict__ abs_out, double* __restrict__ mirror_out,
-                                             long long pix_rot = -1, long long pix_mir = -1, const double* __restrict__ lds_trig = nullptr) {
+                                             long long pix_rot = -1, long long pix_mir = -1) {
   using Z = zk_set<NMAX>;
   // (plane, pix) address the |Z| output; the two others default to the same pixel offset (planes layout) and differ in
   // the rows layout, where a pixel's outputs are rows of (N, n_folds), (N, N_c) and (N)
@@ -169,6 +169,9 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
       // ~m^2 ulp, 1e-13 at m = 24).  A full [angle][2 NMAX] table kept missing the scalar cache (~500 cycles
       // per half row and wave even at 7.4 KB, next to the pixel loop's own tables); this one is 0.7 KB and one
       // scalar load feeds four rows.  The host pads it to a multiple of four rows by repeating the last row.
+      // (Round 3 tried the third place a table can live: [angle][m] pairs (cos m theta, sin m theta) in LDS behind the tile, one
+      //  broadcast ds_read_b128 per m instead of the two recurrence FMAs -- all outputs per 4096^2 at n_max 10: 9.17 -> 9.83 ms,
+      //  n_max 12: 14.8 -> 15.9: a wave-wide 16-byte LDS read costs more than two lane-uniform FMAs.  Not kept.)
       const ZK_CONST double* tr = cs;
       double best8 = -__builtin_inf();
       const int rows4 = (prm.n_theta / 8 + 4) & ~3;
@@ -183,12 +186,8 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
           double x1 = 0.0, x3 = 0.0, y1 = 0.0, y3 = 0.0;
           const double c1 = cs4[2 * j], s1 = cs4[2 * j + 1], two_c1 = c1 + c1;
           double cp_ = 1.0, sp_ = 0.0, c = c1, sn = s1;  // (cos, sin) of (m - 1) theta and m theta
-          // fused kernel (round 3): (cos m theta, sin m theta) of this angle from a table in LDS -- one broadcast ds_read_b128
-          // per m on the LDS pipe instead of the two lane-uniform recurrence FMAs on the float64 pipe
-          const double* __restrict__ lrow = lds_trig ? lds_trig + (i0 + j) * (2 * NMAX) : nullptr;
 #pragma unroll
           for (int m = 1; m <= NMAX; ++m) {  // m = 0 is always unselected (C_0 = S_0 = 0)
-            if (lds_trig) c = lrow[2 * (m - 1)], sn = lrow[2 * (m - 1) + 1];
             if ((m & 3) == 0) k0 = __builtin_fma(Cm[m], c, k0), l0 = __builtin_fma(Sm[m], sn, l0);
             if ((m & 3) == 1)
               k1 = __builtin_fma(Cm[m], c, k1), l1 = __builtin_fma(Sm[m], sn, l1), x1 = __builtin_fma(Cm[m], sn, x1),
@@ -197,7 +196,7 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
             if ((m & 3) == 3)
               k3 = __builtin_fma(Cm[m], c, k3), l3 = __builtin_fma(Sm[m], sn, l3), x3 = __builtin_fma(Cm[m], sn, x3),
               y3 = __builtin_fma(Sm[m], c, y3);
-            if (m < NMAX && !lds_trig) {
+            if (m < NMAX) {
               const double cn_ = __builtin_fma(two_c1, c, -cp_), sn_ = __builtin_fma(two_c1, sn, -sp_);
               cp_ = c;
               sp_ = sn;
@@ -269,7 +268,7 @@ __global__ __launch_bounds__(256, ZK_MAPS_WAVES(NMAX)) void zk_frame_maps_kernel
     const T* __restrict__ img, const zk_sep_row* __restrict__ rows, const double* __restrict__ xq,
     const double* __restrict__ tmat, const double* __restrict__ trig, double* __restrict__ rot_out,
     double* __restrict__ abs_out, double* __restrict__ mirror_out, zk_maps_params prm, int n_tab_rows, int K, int H,
-    int W, int row0, int n_rows, int tile_pitch, long long plane, int trig_lds) {
+    int W, int row0, int n_rows, int tile_pitch, long long plane) {
   using Z = zk_set<NMAX>;
   extern __shared__ __attribute__((aligned(16))) double tile[];
   const int tid = threadIdx.x;
@@ -281,14 +280,7 @@ __global__ __launch_bounds__(256, ZK_MAPS_WAVES(NMAX)) void zk_frame_maps_kernel
   const int tile_elems = (K + 3) * tile_pitch;
 
   zk_stage_tile(tile, img, H, W, i0 - ea, k0 - ea, K + 3, tile_pitch);
-  // eighth-grid mirror scan: its (cos m theta, sin m theta) rows go into LDS behind the tile (host-built, maps_setup)
-  const int rows4 = (prm.n_theta / 8 + 4) & ~3;
-  double* const ltrig = tile + tile_elems;
-  const bool use_ltrig = mirror_out != nullptr && prm.theta_sym == 2 && trig_lds;
-  if (use_ltrig) {
-    const double* __restrict__ src = trig + ZK_MAX_FOLDS * ZK_MAPS_WROW + 2 * rows4 + 16;
-    for (int e = tid; e < rows4 * 2 * NMAX; e += 256) ltrig[e] = src[e];
-  }
+  (void)tile_elems;
   __syncthreads();
 
   zk_sep_acc<NMAX> acc;
@@ -320,7 +312,7 @@ __global__ __launch_bounds__(256, ZK_MAPS_WAVES(NMAX)) void zk_frame_maps_kernel
         A = acc.template moment<Z::slot_of(n, am)>(tb);
         if constexpr (am > 0) B = acc.template moment<Z::slot_of(n, -am)>(tb);
       },
-      prm, trig, live, plane, pix, rot_out, abs_out, mirror_out, -1, -1, use_ltrig ? ltrig : nullptr);
+      prm, trig, live, plane, pix, rot_out, abs_out, mirror_out);
 }
 
 // Planes form (plans whose moments come out of several kernel launches, n_max > 16): one lane per pixel,
@@ -385,10 +377,7 @@ int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, i
                const zk_maps_params& prm, const double* d_trig, double* rot, double* ab, double* mirror,
                hipStream_t s) {
   const zk_sep_tables* t = p->sep;
-  static const bool no_ltrig = getenv("ZK_MAPS_NO_LDS_TRIG") != nullptr;  // A/B runs: the recurrence on the vector pipe
-  const int trig_lds = mirror && prm.theta_sym == 2 && !no_ltrig;
-  const size_t lds = (size_t)(p->size + 3) * t->tile_pitch * sizeof(double) +
-                     (trig_lds ? (size_t)((prm.n_theta / 8 + 4) & ~3) * 2 * NMAX * sizeof(double) : 0);
+  const size_t lds = (size_t)(p->size + 3) * t->tile_pitch * sizeof(double);
   auto kern = zk_frame_maps_kernel<NMAX, T>;
   if (lds > 64 * 1024)
     ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -399,7 +388,7 @@ int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, i
     if (rc) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, t->d_rows, t->d_xq, t->d_T, d_trig,
                        rot ? rot + off : nullptr, ab ? ab + off : nullptr, mirror ? mirror + off : nullptr, prm, t->n_rows,
-                       p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane, trig_lds);
+                       p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane);
     ZK_HIP(hipGetLastError());
     return zk_prof_end(p, s);
   });
@@ -646,16 +635,6 @@ static int maps_setup(zk_plan* p, const int32_t* folds, int n_folds, const int32
         tr[2 * i + 1] = sin(theta[k]);
       }
       for (size_t z = 2 * (size_t)rows4; z < 2 * (size_t)rows4 + 16; ++z) tr[z] = 0.0;
-      // then, for the fused kernel's LDS table: [rows4][knm] pairs (cos m theta_i, sin m theta_i), m = 1 .. knm
-      const size_t full0 = tab.size();
-      tab.resize(full0 + (size_t)rows4 * 2 * knm);
-      for (int i = 0; i < rows4; ++i) {
-        const int k = i < last ? i : last;
-        for (int m = 1; m <= knm; ++m) {
-          tab[full0 + (size_t)i * 2 * knm + 2 * (m - 1)] = cos((double)m * theta[k]);
-          tab[full0 + (size_t)i * 2 * knm + 2 * (m - 1) + 1] = sin((double)m * theta[k]);
-        }
-      }
     } else
     for (int i = 0; i < n_theta; ++i)
       for (int m = 0; m <= knm; ++m) {
