@@ -86,9 +86,11 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
     const double a2 = A * A, b2 = B * B;
     if (abs_out != nullptr && live && n <= prm.plan_nmax)
       abs_out[Z::complex_index(n, am) * plane + pix] = __builtin_sqrt(a2 + b2);
-    Em[am] += a2 + b2;
-    Cm[am] += a2 - b2;
-    Sm[am] = __builtin_fma(2.0 * A, B, Sm[am]);
+    if constexpr (am > 0) {  // m = 0 is never selected (the host insists on it in m_unselect): its sums are not kept at all
+      Em[am] += a2 + b2;
+      Cm[am] += a2 - b2;
+      Sm[am] = __builtin_fma(2.0 * A, B, Sm[am]);
+    }
   };
 
   if constexpr (BY_ORDER) {
@@ -109,21 +111,42 @@ __device__ __forceinline__ void zk_maps_tail(GET&& get, const zk_maps_params& pr
         if (am <= n && ((n - am) & 1) == 0) {  // wave-uniform
           const double a2 = A[am] * A[am], b2 = B[am] * B[am];
           if (abs_out != nullptr && live) abs_out[Z::complex_index(n, am) * plane + pix] = __builtin_sqrt(a2 + b2);
-          Em[am] += a2 + b2;
-          Cm[am] += a2 - b2;
-          Sm[am] = __builtin_fma(2.0 * A[am], B[am], Sm[am]);
+          if (am > 0) {
+            Em[am] += a2 + b2;
+            Cm[am] += a2 - b2;
+            Sm[am] = __builtin_fma(2.0 * A[am], B[am], Sm[am]);
+          }
         }
       }
     }
   } else {
     // +m and -m of one (n, |m|) are produced back to back (they live in partner parity classes of the T
     // product) and folded into the running sums at once, so no moment outlives its own combine().
+    // Even |m| first, then odd |m|: Z_{n,+m} and Z_{n,-m} of an even m come from the classes EE and OO of the T product, of an
+    // odd m from OE and EO -- after the first pass half of the 3 (n_max + 1)(n_max + 2) / 2 ... sums M of the pixel loop are dead
+    // and the second pass has their registers (the n_max 10 instance, capped at 256 registers for two waves per SIMD, spilled
+    // 404 bytes per lane with the (n, |m|) pairs in index order).  Inside a pass the orders n run DOWNWARDS: Z_n only uses the
+    // sums M_(a,b) with a + b <= n, so those with a + b = n die with order n while the per-|m| sums grow.
     zk_for_each_int(
         [&](auto k) {
-          constexpr int n = Z::complex_n(decltype(k)::value), am = Z::complex_m(decltype(k)::value);
-          double A, B = 0.0;
-          get(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
-          combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
+          constexpr int kk = Z::NC - 1 - decltype(k)::value;  // highest order first: see below
+          constexpr int n = Z::complex_n(kk), am = Z::complex_m(kk);
+          if constexpr ((am & 1) == 0) {
+            double A, B = 0.0;
+            get(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
+            combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
+          }
+        },
+        std::make_integer_sequence<int, Z::NC>{});
+    zk_for_each_int(
+        [&](auto k) {
+          constexpr int kk = Z::NC - 1 - decltype(k)::value;
+          constexpr int n = Z::complex_n(kk), am = Z::complex_m(kk);
+          if constexpr ((am & 1) == 1) {
+            double A, B = 0.0;
+            get(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
+            combine(std::integral_constant<int, n>{}, std::integral_constant<int, am>{}, A, B);
+          }
         },
         std::make_integer_sequence<int, Z::NC>{});
   }
