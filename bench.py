@@ -317,6 +317,11 @@ def worker(args):
     from mtflearn_amd import distributed as D
     from mtflearn_amd.synthetic import honeycomb_frame
 
+    if (os.environ.get("ZK_BENCH_ONE_DEVICE") and backend == "rccl" and world > 1 and "NCCL_HOSTID" not in os.environ
+            and not os.environ.get("ZK_BENCH_SAME_HOSTID")):
+        # the one-GPU rehearsal under an outside launcher (python -m torch.distributed.run ... bench.py --gpus N, the driver's
+        # form): the launcher did not give the ranks their host ids, so each takes its own before RCCL is initialised
+        os.environ.update(D.one_gpu_rank_env(rank, {}))
     dead = Deadman(rank, world, json_fd, args)
     limit = float(os.environ.get("ZK_BENCH_PHASE_TIMEOUT", os.environ.get("ZK_BENCH_SIDE_TIMEOUT", "420")))
     comm = None
