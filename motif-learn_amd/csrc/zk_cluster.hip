@@ -49,6 +49,9 @@ struct zk_rows {
   size_t resp_bytes = 0;
   unsigned long long* d_count = nullptr;  // [4] integer counters
   std::vector<double> h_buf;
+  void* h_pin = nullptr;         // page-locked staging of the operand tables (up) and the reduced results (down)
+  size_t pin_bytes = 0;
+  hipEvent_t ev_up = nullptr;    // the last table upload has left the staging buffer
   bool profile = false;          // HIP events around the main kernel of zk_kmeans_step / zk_gmm_estep / zk_gmm_moments
   hipEvent_t ev[2] = {nullptr, nullptr};
   double last_kernel_ms = 0.0;
@@ -947,12 +950,32 @@ int row_grid(const zk_rows* m, size_t lds_bytes) {
 
 int ensure(void** buf, size_t* have, size_t need) { return zk_ensure(buf, have, need); }
 
+// page-locked staging area of at least `need` bytes (tables are a few KiB to ~100 KiB)
+int ensure_pinned(zk_rows* m, size_t need) {
+  if (m->pin_bytes >= need) return 0;
+  if (m->ev_up) ZK_HIP(hipEventSynchronize(m->ev_up));
+  if (m->h_pin) (void)hipHostFree(m->h_pin);
+  m->h_pin = nullptr;
+  m->pin_bytes = 0;
+  const size_t want = need < 65536 ? 65536 : need;
+  ZK_HIP(hipHostMalloc(&m->h_pin, want, hipHostMallocDefault));
+  m->pin_bytes = want;
+  if (!m->ev_up) ZK_HIP(hipEventCreateWithFlags(&m->ev_up, hipEventDisableTiming));
+  return 0;
+}
+
+// the operand tables of a pass: staged in page-locked memory, so the copy is asynchronous and ordered before the pass's kernels on
+// the stream -- no synchronisation here (round 3; a pageable source plus hipStreamSynchronize cost every pass ~25 us of its
+// ~100 us of host overhead).  The staging buffer is reused once the previous upload has left it (ev_up).
 int upload_tab(zk_rows* m, const std::vector<double>& h) {
-  int rc = ensure(&m->d_tab, &m->tab_bytes, h.size() * sizeof(double));
+  const size_t bytes = h.size() * sizeof(double);
+  int rc = ensure(&m->d_tab, &m->tab_bytes, bytes);
   if (rc) return rc;
-  // pageable source: the copy is complete (staged) when the call returns, and ordered before later work on the stream
-  ZK_HIP(hipMemcpyAsync(m->d_tab, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, m->stream));
-  ZK_HIP(hipStreamSynchronize(m->stream));
+  if ((rc = ensure_pinned(m, bytes))) return rc;
+  ZK_HIP(hipEventSynchronize(m->ev_up));  // (complete long ago: every pass ends with a synchronised read-back)
+  memcpy(m->h_pin, h.data(), bytes);
+  ZK_HIP(hipMemcpyAsync(m->d_tab, m->h_pin, bytes, hipMemcpyHostToDevice, m->stream));
+  ZK_HIP(hipEventRecord(m->ev_up, m->stream));
   return 0;
 }
 
@@ -1031,6 +1054,8 @@ extern "C" int zk_rows_destroy(zk_rows* m) {
     if (b) (void)hipFree(b);
   for (hipEvent_t e : m->ev)
     if (e) (void)hipEventDestroy(e);
+  if (m->ev_up) (void)hipEventDestroy(m->ev_up);
+  if (m->h_pin) (void)hipHostFree(m->h_pin);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return 0;
