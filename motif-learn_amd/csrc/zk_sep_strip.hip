@@ -392,6 +392,12 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
   }
 }
 
+// Also tried in round 3: requesting a sweep's FIRST operands ahead of the row step that precedes it (each of the 66 sweeps of an
+// output pair starts with an exposed scalar + LDS round trip).  The request then has to stay in flight across the row step's
+// 45 FMAs, and the compiler, short of SGPRs there, COPIES the not-yet-written registers of the request to other registers
+// (tools/check_async_requests.py: 1 516 hazards; across the loop's back edge it even wants the 16-SGPR tuple in vector
+// registers: "illegal VGPR to SGPR copy").  An in-flight request is only safe over straight-line code without register
+// pressure, which is what the one-block-ahead pipeline inside a sweep is.
 // Tried in round 3 and not kept: a PERSISTENT form (two workgroups per CU walking the tiles, the next tile's raw rows copied by
 // the LDS-DMA engine under the current tile's arithmetic, widened to float64 at the tile switch; the DMA wait placed before the
 // tile's stores, bare s_barrier instead of __syncthreads() -- whose fence waits for the 90 outstanding stores per lane -- and
