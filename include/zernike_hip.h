@@ -438,6 +438,10 @@ int zk_rows_knn_correlation(zk_rows* rows, int n_neighbors, int local_connectivi
 /* numpy.random.RandomState.choice(n, p = uniform) from its one uniform draw u (host arithmetic, no n-sized arrays): the first
  * seed of scikit-learn's k-means++. */
 int zk_uniform_choice_index(int64_t n, double u, int64_t* index_out);
+/* test hooks of the above: the same index by plain sequential additions (and the last cumulative sum), and the float64 sum of
+ * `steps` sequential additions of c -- what numpy.cumsum of a constant array holds at index steps - 1 -- by the jumping method */
+int zk_uniform_choice_index_sequential(int64_t n, double u, int64_t* index_out, double* last_out);
+double zk_repeated_sum_f64(double c, int64_t steps);
 int zk_force_layout_stage(double* xy, int64_t n_nodes, const int64_t* node1, const int64_t* node2, const double* weight,
                           int64_t n_pairs, const int64_t* nbrs_ind, int n_neighbors, int64_t num_iterations,
                           const double* force_params, int num_negative_samples, double learning_rate, int64_t* rng_state,

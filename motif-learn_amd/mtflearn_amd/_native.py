@@ -126,6 +126,8 @@ SYMBOLS = {
     "zk_rows_gram": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "zk_rows_knn_correlation": (c_int, [c_void_p, c_int, c_int, c_double, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     "zk_uniform_choice_index": (c_int, [c_int64, c_double, POINTER(c_int64)]),
+    "zk_uniform_choice_index_sequential": (c_int, [c_int64, c_double, POINTER(c_int64), POINTER(c_double)]),
+    "zk_repeated_sum_f64": (c_double, [c_double, c_int64]),
     "zk_force_layout_stage": (c_int, [POINTER(c_double), c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_double), c_int64,
                                       POINTER(c_int64), c_int, c_int64, POINTER(c_double), c_int, c_double, POINTER(c_int64),
                                       POINTER(c_double)]),

@@ -82,3 +82,31 @@ def test_uniform_choice_is_numpy_choice():
         cdf /= cdf[-1]
         for u in (0.0, np.nextafter(1.0, 0.0), 0.5, 1.0 / n, np.nextafter(1.0 / n, 0), cdf[n // 3], np.nextafter(cdf[n // 3], 0)):
             assert _uniform_choice(Fixed(u), n) == cdf.searchsorted(u, side="right"), (n, u)
+
+
+def test_repeated_sum_jumps_equal_numpy_cumsum():
+    """zk_uniform_choice_index no longer walks the n dependent additions of numpy.cumsum: inside a binade every addition of
+    the same constant rounds the same way, so it jumps.  The jumped sums must be numpy's, bit for bit -- constants with and
+    without exact ties, at every index of small arrays and at random indices of large ones -- and the index must be the
+    sequential replay's."""
+    from ctypes import byref, c_double, c_int64
+    from mtflearn_amd import _native
+    lib = _native.load()
+    rng = np.random.default_rng(12)
+    consts = [1.0 / n for n in (3, 7, 10, 1000, 4097, 65537, 4068289, 16524225)] + [0.1, 1.0, 2.0 ** -20, 1.5 * 2.0 ** -30, 3.0 * 2.0 ** -40,
+              float(np.nextafter(0.25, 1)), 1e-300, 1e300 / 3, float(rng.random()), float(rng.random()) * 1e-9]
+    for c in consts:
+        cs = np.full(70000, c).cumsum()
+        for i in list(range(0, 600)) + list(rng.integers(600, 70000, 200)):
+            assert lib.zk_repeated_sum_f64(c, int(i) + 1) == cs[i], (c, i)
+    for n in (4068289, 16524225, (1 << 22) + 1):                       # the sizes the bench runs: the last sum and random indices
+        c = 1.0 / n
+        cs = np.full(n, c).cumsum()
+        assert lib.zk_repeated_sum_f64(c, n) == cs[-1]
+        for i in rng.integers(0, n, 300):
+            assert lib.zk_repeated_sum_f64(c, int(i) + 1) == cs[i], (n, i)
+        for u in list(rng.random(20)) + [0.0, float(np.nextafter(1.0, 0.0))]:
+            a, b, last = c_int64(), c_int64(), c_double()
+            assert lib.zk_uniform_choice_index(n, float(u), byref(a)) == 0
+            assert lib.zk_uniform_choice_index_sequential(n, float(u), byref(b), byref(last)) == 0
+            assert a.value == b.value == (cs / cs[-1]).searchsorted(u, side="right") and last.value == cs[-1]
