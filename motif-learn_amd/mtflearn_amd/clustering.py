@@ -586,8 +586,32 @@ def _gaussian_parameters(sh, k, shift, reg_covar, covariance_type):
     return nk, means, cov
 
 
+_BLAS_CONTROLLER = None
+
+
+def _one_blas_thread():
+    """Context in which the host's BLAS / LAPACK runs on one thread.  The matrices between the passes are D x D: on the 256-CPU
+    host of a GPU box a threaded ``scipy.linalg.solve_triangular`` of a 45 x 45 system takes 2.2 ms (waking its workers),
+    30 of them were 66 of the 72 ms of a four-iteration ``gmm_fit_predict`` on 4 M rows; single-threaded it takes ~20 us.
+    (Same LAPACK routines: every right-hand-side column is solved in the same order either way.)"""
+    global _BLAS_CONTROLLER
+    try:
+        if _BLAS_CONTROLLER is None:
+            from threadpoolctl import ThreadpoolController
+            _BLAS_CONTROLLER = ThreadpoolController()
+        return _BLAS_CONTROLLER.limit(limits=1, user_api="blas")
+    except Exception:                                                        # no threadpoolctl: the plain, threaded calls
+        import contextlib
+        return contextlib.nullcontext()
+
+
 def _precision_cholesky(cov, covariance_type, k, d):
     """``_compute_precision_cholesky`` -> upper-triangular factors (k, D, D) for the E-step kernel + ``log_det``."""
+    with _one_blas_thread():
+        return _precision_cholesky_host(cov, covariance_type, k, d)
+
+
+def _precision_cholesky_host(cov, covariance_type, k, d):
     from scipy import linalg
     out = np.zeros((k, d, d))
 

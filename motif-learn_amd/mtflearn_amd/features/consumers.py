@@ -32,7 +32,9 @@ def _covariance_eigh(gram, n_rows):
     mean = gram[d, :d] / n_rows
     cov = gram[:d, :d] - n_rows * np.outer(mean, mean)
     cov /= n_rows - 1
-    eigenvals, eigenvecs = np.linalg.eigh(cov)
+    from ..clustering import _one_blas_thread
+    with _one_blas_thread():                                   # a D x D problem: threaded LAPACK only pays for waking its workers
+        eigenvals, eigenvecs = np.linalg.eigh(cov)
     eigenvals = np.flip(eigenvals, axis=0).copy()
     eigenvecs = np.flip(eigenvecs, axis=1)
     eigenvals[eigenvals < 0.0] = 0.0
