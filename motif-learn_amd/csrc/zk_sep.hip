@@ -157,15 +157,22 @@ int zk_sep_build(zk_plan* p, const double* basis) {
   for (int j = 0; j < NP; ++j) {
     double vmax = 0.0;
     for (int t = 0; t < K * K; ++t) vmax = std::max(vmax, fabs(basis[(size_t)j * K * K + t]));
-    for (int r = 0; r < K; ++r)
+    // row by row, the y direction first: V_j(r, c) = sum_a [sum_b T_j(a, b) P_b(y_r)] P_a(x_c) -- K (D^2 / 2 + K D) operations
+    // per function instead of K^2 D^2 / 2 (plan creation at (64, 12): 51 -> 12 ms, at (48, 24): 330 -> 50 ms)
+    std::vector<ld> ca(D);
+    for (int r = 0; r < K; ++r) {
+      for (int a = 0; a <= knm; ++a) {
+        ld s = 0.0L;
+        for (int b = 0; a + b <= knm; ++b) s += Tfull[((size_t)j * D + a) * D + b] * P[(size_t)r * D + b];
+        ca[a] = s;
+      }
       for (int c = 0; c < K; ++c) {
         if (!disk[(size_t)r * K + c]) continue;
         ld v = 0.0L;
-        for (int a = 0; a <= knm; ++a)
-          for (int b = 0; a + b <= knm; ++b)
-            v += Tfull[((size_t)j * D + a) * D + b] * P[(size_t)c * D + a] * P[(size_t)r * D + b];
+        for (int a = 0; a <= knm; ++a) v += ca[a] * P[(size_t)c * D + a];
         if (fabsl(v - (ld)basis[((size_t)j * K + r) * K + c]) > tol * (ld)vmax + 1e-300L) return 0;
       }
+    }
   }
 
   // ---- device tables -----------------------------------------------------------------------
