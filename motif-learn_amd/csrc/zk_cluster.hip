@@ -52,6 +52,8 @@ struct zk_rows {
   void* h_pin = nullptr;         // page-locked staging of the operand tables (up) and the reduced results (down)
   size_t pin_bytes = 0;
   hipEvent_t ev_up = nullptr;    // the last table upload has left the staging buffer
+  void* h_res = nullptr;         // page-locked landing area of the reduced results (+ 8 bytes for a counter)
+  size_t res_bytes = 0;
   bool profile = false;          // HIP events around the main kernel of zk_kmeans_step / zk_gmm_estep / zk_gmm_moments
   hipEvent_t ev[2] = {nullptr, nullptr};
   double last_kernel_ms = 0.0;
@@ -981,8 +983,19 @@ int upload_tab(zk_rows* m, const std::vector<double>& h) {
 
 // fixed-order sum of the per-workgroup partial results ([n_blocks][n] in d_part) -> host; two levels (groups of 32 blocks,
 // then the groups) so that thousands of partials do not become one thread's serial loop
-int reduce_to_host(zk_rows* m, int n_blocks, int n, double* host_out) {
+int reduce_to_host(zk_rows* m, int n_blocks, int n, double* host_out, unsigned long long* counter_out = nullptr) {
   const int group = 32, n_groups = (n_blocks + group - 1) / group;
+  {  // results land in page-locked memory: the copies are asynchronous and ONE synchronisation ends the pass
+    const size_t need = (size_t)n * sizeof(double) + sizeof(unsigned long long);
+    if (m->res_bytes < need) {
+      if (m->h_res) (void)hipHostFree(m->h_res);
+      m->h_res = nullptr;
+      m->res_bytes = 0;
+      const size_t want = need < 16384 ? 16384 : need;
+      ZK_HIP(hipHostMalloc(&m->h_res, want, hipHostMallocDefault));
+      m->res_bytes = want;
+    }
+  }
   int rc = ensure(&m->d_red, &m->red_bytes, (size_t)(n_groups + 1) * n * sizeof(double));
   if (rc) return rc;
   double* fin = (double*)m->d_red;
@@ -996,8 +1009,13 @@ int reduce_to_host(zk_rows* m, int n_blocks, int n, double* host_out) {
                        fin);
   }
   ZK_HIP(hipGetLastError());
-  ZK_HIP(hipMemcpyAsync(host_out, fin, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  ZK_HIP(hipMemcpyAsync(m->h_res, fin, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  if (counter_out)
+    ZK_HIP(hipMemcpyAsync((char*)m->h_res + (size_t)n * sizeof(double), m->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                          m->stream));
   ZK_HIP(hipStreamSynchronize(m->stream));
+  memcpy(host_out, m->h_res, (size_t)n * sizeof(double));
+  if (counter_out) memcpy(counter_out, (char*)m->h_res + (size_t)n * sizeof(double), sizeof(unsigned long long));
   return 0;
 }
 
@@ -1056,6 +1074,7 @@ extern "C" int zk_rows_destroy(zk_rows* m) {
     if (e) (void)hipEventDestroy(e);
   if (m->ev_up) (void)hipEventDestroy(m->ev_up);
   if (m->h_pin) (void)hipHostFree(m->h_pin);
+  if (m->h_res) (void)hipHostFree(m->h_res);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return 0;
@@ -1355,8 +1374,7 @@ extern "C" int zk_kmeans_step(zk_rows* m, const double* centers, int k, int upda
   unsigned long long chg = 0;
   if (update) {
     std::vector<double> red((size_t)k * D1);
-    ZK_HIP(hipMemcpyAsync(&chg, m->d_count, sizeof(chg), hipMemcpyDeviceToHost, m->stream));
-    if ((rc = reduce_to_host(m, grid, k * D1, red.data()))) return rc;
+    if ((rc = reduce_to_host(m, grid, k * D1, red.data(), &chg))) return rc;  // sums and the changed-label count: one wait
     for (int c = 0; c < k; ++c) {
       for (int j = 0; j < m->D; ++j) sums_out[(size_t)c * m->D + j] = red[(size_t)c * D1 + j];
       counts_out[c] = red[(size_t)c * D1 + m->D];
