@@ -14,6 +14,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include <hipfft/hipfft.h>  // types and prototypes only; nothing here links against libhipfft
 
@@ -71,16 +73,53 @@ int fft_load() {
     if (zk_f_ != HIPFFT_SUCCESS) return zk_fail(ZK_E_FFT, std::string(#call) + " failed with hipfftResult " + std::to_string((int)zk_f_)); \
   } while (0)
 
-// a batched 2-D complex plan that destroys itself
+// Batched 2-D complex plans are kept between calls (round 3): building one costs milliseconds even when rocFFT has its
+// kernels already, and the pickers are called with the same shapes over and over (every window batch of one frame size, every
+// patch set of one size).  A plan in use is checked out of the cache and goes back when its holder dies; the cache keeps the
+// four most recently returned ones and destroys what falls out.
+struct fft_cached {
+  int device, ny, nx, batch;
+  hipfftHandle h;
+};
+static std::mutex g_fft_cache_mutex;
+static std::vector<fft_cached> g_fft_cache;  // most recently returned last
+
 struct fft_plan {
   hipfftHandle h = 0;
   bool live = false;
+  fft_cached key = {};
   ~fft_plan() {
-    if (live) (void)g_fft.Destroy(h);
+    if (!live) return;
+    hipfftHandle drop = 0;
+    bool have_drop = false;
+    {
+      std::lock_guard<std::mutex> lock(g_fft_cache_mutex);
+      g_fft_cache.push_back(key);
+      if (g_fft_cache.size() > 4) {
+        drop = g_fft_cache.front().h;
+        have_drop = true;
+        g_fft_cache.erase(g_fft_cache.begin());
+      }
+    }
+    if (have_drop) (void)g_fft.Destroy(drop);
   }
   int make(int ny, int nx, int batch) {
+    int device = 0;
+    ZK_HIP(hipGetDevice(&device));
+    {
+      std::lock_guard<std::mutex> lock(g_fft_cache_mutex);
+      for (size_t i = g_fft_cache.size(); i-- > 0;)
+        if (g_fft_cache[i].device == device && g_fft_cache[i].ny == ny && g_fft_cache[i].nx == nx && g_fft_cache[i].batch == batch) {
+          key = g_fft_cache[i];
+          h = key.h;
+          live = true;
+          g_fft_cache.erase(g_fft_cache.begin() + (long)i);
+          return 0;
+        }
+    }
     int n[2] = {ny, nx};
     ZK_FFT(g_fft.PlanMany(&h, 2, n, nullptr, 1, ny * nx, nullptr, 1, ny * nx, HIPFFT_Z2Z, batch));
+    key = fft_cached{device, ny, nx, batch, h};
     live = true;
     return 0;
   }
