@@ -944,7 +944,9 @@ size_t tile_lds(const zk_rows* m, int nbuf) { return (size_t)nbuf * TILE * m->D 
 
 // persistent single-wave workgroups: as many per CU as the LDS tile allows (at most 8), never more than tiles
 int row_grid(const zk_rows* m, size_t lds_bytes) {
-  int per_cu = (int)((160 * 1024) / (lds_bytes + 512));
+  // (LDS is handed out in 512-byte granules: a 64 x 45 tile of doubles is exactly 45 of them, and SEVEN fit a CU's 160 KiB)
+  static const int margin = getenv("ZK_ROW_GRID_MARGIN") ? atoi(getenv("ZK_ROW_GRID_MARGIN")) : 0;
+  int per_cu = (int)((160 * 1024) / (((lds_bytes + 511) & ~(size_t)511) + margin));
   per_cu = std::max(1, std::min(per_cu, 8));
   const long long tiles = (m->N + TILE - 1) / TILE;
   return (int)std::min<long long>(tiles, (long long)per_cu * m->n_cu);
