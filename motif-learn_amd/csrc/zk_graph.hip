@@ -171,7 +171,8 @@ typedef double zk_v4d __attribute__((ext_vector_type(4)));
 #define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-// unit rows in the blocked layout, `steps` = ceil(D / 4) feature steps, rows padded with zeros to `Np` (a multiple of 64)
+// unit rows in the blocked layout: `steps` feature steps of four (the kernel instance that holds D, zero features beyond it), rows
+// padded with zeros to `Np` (a multiple of 64)
 __global__ __launch_bounds__(256) void unit_rows_blocked_kernel(const double* __restrict__ X, long long N, int D, long long Np, int steps,
                                                                 double* __restrict__ Zb) {
   const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
