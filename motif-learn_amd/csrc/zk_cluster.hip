@@ -577,8 +577,8 @@ __global__ __launch_bounds__(64 * ZK_EWAVES) void estep_kernel(const double* __r
 // lane = (row, slot): slot s takes the exponentials of the components c = s (mod 4).
 // FULL: every piece of the upper triangle ('full' / 'tied' factors); else only the four diagonal pieces of a column block
 // ('diag' / 'spherical' factors: the host looks at the factors it was given).
-template <int NB, bool FULL>
-__global__ __launch_bounds__(512, 2) void estep_mfma_kernel(const double* __restrict__ X, long long N, int D, const double* __restrict__ tabP,
+template <int NB, bool FULL, int NW>
+__global__ __launch_bounds__(64 * NW) void estep_mfma_kernel(const double* __restrict__ X, long long N, int D, const double* __restrict__ tabP,
                                                             const double* __restrict__ tabB /* [k][NB][16]: -mu P */,
                                                             const double* __restrict__ cst, double dlog2pi, int k,
                                                             double* __restrict__ resp, int32_t* __restrict__ labels,
@@ -596,10 +596,10 @@ __global__ __launch_bounds__(512, 2) void estep_mfma_kernel(const double* __rest
   double* const sqt = mine + 16 * D + 4;
   {  // the factor table: one cooperative copy
     const long long n = (long long)k * PSTEPS * 64 + k * NB * 16;
-    for (long long e = threadIdx.x; e < n; e += 512) lds[e] = e < (long long)k * PSTEPS * 64 ? tabP[e] : tabB[e - (long long)k * PSTEPS * 64];
+    for (long long e = threadIdx.x; e < n; e += 64 * NW) lds[e] = e < (long long)k * PSTEPS * 64 ? tabP[e] : tabB[e - (long long)k * PSTEPS * 64];
   }
-  const long long n_blocks = (N + 15) / 16, stride = (long long)gridDim.x * 8;
-  long long b = (long long)blockIdx.x * 8 + wave;
+  const long long n_blocks = (N + 15) / 16, stride = (long long)gridDim.x * NW;
+  long long b = (long long)blockIdx.x * NW + wave;
   const int n_gran = 8 * D;  // 16-byte granules of a block
   auto issue = [&](long long bb) {
     if ((bb + 1) * 16 > N) return;  // the ragged last block is copied with ordinary loads
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(512, 2) void estep_mfma_kernel(const double* __rest
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
-    for (int w = 0; w < 8; ++w) t += lds[w];
+    for (int w = 0; w < NW; ++w) t += lds[w];
     part[blockIdx.x] = t;
   }
 }
@@ -1527,10 +1527,17 @@ extern "C" int zk_gmm_estep(zk_rows* m, const double* prec_chol, const double* m
     int rc = upload_tab(m, h);
     h.clear();
     if (rc) return rc;
-    const size_t lds = ((size_t)k * psteps * 64 + (size_t)k * NB * 16 + 8 * ((size_t)16 * D + 4 + 128)) * sizeof(double);
+    // twelve waves per workgroup (three per SIMD) while the factors and the waves' row blocks fit a CU's LDS, else eight: the
+    // chains are 4 / 8 / 12 MFMAs long, and short dependent chains gain from a third wave (tools/micro_mfma64_chain.hip)
+    static const int forced_nw = getenv("ZK_ESTEP_WAVES") ? atoi(getenv("ZK_ESTEP_WAVES")) : 0;
+    const size_t lds_tab = ((size_t)k * psteps * 64 + (size_t)k * NB * 16) * sizeof(double);
+    const size_t lds_wave = ((size_t)16 * D + 4 + 128) * sizeof(double);
+    int nw = lds_tab + 12 * lds_wave <= 160 * 1024 ? 12 : 8;
+    if (forced_nw == 8 || (forced_nw == 12 && nw == 12)) nw = forced_nw;
+    const size_t lds = lds_tab + nw * lds_wave;
     if ((rc = check_lds(lds))) return rc;
     const long long n_blocks = (m->N + 15) / 16;
-    const int grid = (int)std::min<long long>((n_blocks + 7) / 8, (long long)m->n_cu);
+    const int grid = (int)std::min<long long>((n_blocks + nw - 1) / nw, (long long)m->n_cu);
     if ((rc = ensure(&m->d_part, &m->part_bytes, (size_t)grid * sizeof(double)))) return rc;
     if (want_resp && (rc = ensure(&m->d_resp, &m->resp_bytes, (size_t)k * m->N * sizeof(double)))) return rc;
     if (!m->d_labels) ZK_HIP(hipMalloc((void**)&m->d_labels, (size_t)m->N * sizeof(int32_t)));
@@ -1538,11 +1545,16 @@ extern "C" int zk_gmm_estep(zk_rows* m, const double* prec_chol, const double* m
     const double* d_tb = tab + (size_t)k * psteps * 64;
     const double* d_tc = d_tb + (size_t)k * NB * 16;
     if ((rc = prof_begin(m))) return rc;
-#define ZK_ESTEP_LAUNCH(NBV, FULLV)                                                                                                     \
+#define ZK_ESTEP_LAUNCH_NW(NBV, FULLV, NWV)                                                                                             \
   {                                                                                                                                     \
-    if ((rc = allow_lds(estep_mfma_kernel<NBV, FULLV>, lds))) return rc;                                                                \
-    hipLaunchKernelGGL((estep_mfma_kernel<NBV, FULLV>), dim3(grid), dim3(512), lds, m->stream, m->X, (long long)m->N, D, tab, d_tb, d_tc, \
-                       (double)D * std::log(2.0 * M_PI), k, want_resp ? (double*)m->d_resp : nullptr, m->d_labels, (double*)m->d_part); \
+    if ((rc = allow_lds(estep_mfma_kernel<NBV, FULLV, NWV>, lds))) return rc;                                                           \
+    hipLaunchKernelGGL((estep_mfma_kernel<NBV, FULLV, NWV>), dim3(grid), dim3(64 * NWV), lds, m->stream, m->X, (long long)m->N, D, tab, \
+                       d_tb, d_tc, (double)D * std::log(2.0 * M_PI), k, want_resp ? (double*)m->d_resp : nullptr, m->d_labels,          \
+                       (double*)m->d_part);                                                                                             \
+  }
+#define ZK_ESTEP_LAUNCH(NBV, FULLV)                                      \
+  {                                                                      \
+    if (nw == 12) ZK_ESTEP_LAUNCH_NW(NBV, FULLV, 12) else ZK_ESTEP_LAUNCH_NW(NBV, FULLV, 8) \
   }
     if (NB == 1) {
       if (diag) ZK_ESTEP_LAUNCH(1, false) else ZK_ESTEP_LAUNCH(1, true)
@@ -1552,6 +1564,7 @@ extern "C" int zk_gmm_estep(zk_rows* m, const double* prec_chol, const double* m
       if (diag) ZK_ESTEP_LAUNCH(3, false) else ZK_ESTEP_LAUNCH(3, true)
     }
 #undef ZK_ESTEP_LAUNCH
+#undef ZK_ESTEP_LAUNCH_NW
     ZK_HIP(hipGetLastError());
     if ((rc = prof_end(m))) return rc;
     if ((rc = reduce_to_host(m, grid, 1, lse_sum_out))) return rc;
