@@ -532,3 +532,105 @@ class Comm:
         recv = ctypes.create_string_buffer(n * self.world)
         check(self._lib.zk_comm_allgather_host(self._h, send, recv, n), "zk_comm_allgather_host")
         return [recv.raw[r * n:(r + 1) * n] for r in range(self.world)]
+
+
+class _DeviceRef:
+    """What ``array.device`` answers for a :class:`DeviceArray` (``.index``, ``.type``: the attributes the drivers read)."""
+    type = "cuda"
+
+    def __init__(self, index):
+        self.index = int(index)
+
+    def __repr__(self):
+        return f"device(index={self.index})"
+
+
+class DeviceArray:
+    """A C-contiguous array in device memory, allocated through the library (``zk_device_malloc``) -- what the device entry
+    points and the sharded drivers of :mod:`mtflearn_amd.distributed` run on when torch is not used at all.  It offers the few
+    attributes those functions read from an operand (``shape``, ``dtype``, ``device.index``, ``data_ptr()``, ``numel()``,
+    ``element_size()``, ``is_cuda``, ``is_contiguous()``) and views of whole leading-axis items (``a[i]``, ``a[lo:hi]``).
+    Work on it runs on the device's default stream (stream 0)."""
+    is_cuda = True
+
+    def __init__(self, shape, dtype=np.float64, device=0, _base=None, _ptr=0):
+        self.shape = tuple(int(v) for v in (shape if hasattr(shape, "__len__") else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.device = _DeviceRef(device)
+        self._base = _base                       # the owning array of a view
+        if _base is None:
+            ptr = c_void_p()
+            check(load().zk_device_malloc(self.device.index, max(self.nbytes, 16), byref(ptr)), "zk_device_malloc")
+            self._ptr = int(ptr.value)
+        else:
+            self._ptr = int(_ptr)
+
+    # ---- the tensor-like surface ----
+    @property
+    def nbytes(self):
+        return self.numel() * self.dtype.itemsize
+
+    def numel(self):
+        return int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+
+    def element_size(self):
+        return self.dtype.itemsize
+
+    def data_ptr(self):
+        return self._ptr
+
+    def is_contiguous(self):
+        return True
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, key):
+        if not self.shape:
+            raise IndexError("a 0-d DeviceArray has no items")
+        n = self.shape[0]
+        item = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
+        owner = self if self._base is None else self._base
+        if isinstance(key, (int, np.integer)):
+            i = int(key) + (n if key < 0 else 0)
+            if not 0 <= i < n:
+                raise IndexError(f"index {key} out of range for axis 0 with size {n}")
+            return DeviceArray(self.shape[1:], self.dtype, self.device.index, _base=owner, _ptr=self._ptr + i * item)
+        if isinstance(key, slice):
+            lo, hi, step = key.indices(n)
+            if step != 1:
+                raise IndexError("only contiguous slices of the leading axis are views")
+            hi = max(hi, lo)
+            return DeviceArray((hi - lo,) + self.shape[1:], self.dtype, self.device.index, _base=owner, _ptr=self._ptr + lo * item)
+        raise IndexError("DeviceArray views take an integer or a contiguous slice of the leading axis")
+
+    # ---- host <-> device ----
+    @classmethod
+    def from_numpy(cls, array, device=0):
+        array = np.ascontiguousarray(array)
+        out = cls(array.shape, array.dtype, device)
+        if array.nbytes:
+            check(load().zk_device_copy(out.device.index, c_void_p(out._ptr), array.ctypes.data_as(c_void_p), array.nbytes, 1), "zk_device_copy")
+        return out
+
+    def numpy(self):
+        """A host copy (the device is synchronised first: pending work on any stream of it has written its results)."""
+        check(load().zk_device_synchronize(self.device.index), "zk_device_synchronize")
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            check(load().zk_device_copy(self.device.index, out.ctypes.data_as(c_void_p), c_void_p(self._ptr), out.nbytes, 2), "zk_device_copy")
+        return out
+
+    def fill_(self, value):
+        """Fill with a constant (through a host array: a test / set-up helper, not a fast path)."""
+        host = np.full(self.shape, value, dtype=self.dtype)
+        if host.nbytes:
+            check(load().zk_device_copy(self.device.index, c_void_p(self._ptr), host.ctypes.data_as(c_void_p), host.nbytes, 1), "zk_device_copy")
+        return self
+
+    def close(self):
+        if self._base is None and getattr(self, "_ptr", 0):
+            load().zk_device_free(self.device.index, c_void_p(self._ptr))
+            self._ptr = 0
+
+    __del__ = close

@@ -68,13 +68,42 @@ def _chunk_bounds(padded: int, n_chunks: int):
     return [(edges[c], edges[c + 1]) for c in range(n_chunks) if edges[c + 1] > edges[c]]
 
 
+def _is_native(array):
+    """A :class:`mtflearn_amd._native.DeviceArray` (device memory of the library's own, no torch involved)?"""
+    return isinstance(array, _native.DeviceArray)
+
+
+def _empty_like(shape, like):
+    """Uninitialised float64 device array of ``shape`` on ``like``'s device, of ``like``'s kind."""
+    if _is_native(like):
+        return _native.DeviceArray(shape, np.float64, like.device.index)
+    import torch
+    return torch.empty(shape, dtype=torch.float64, device=like.device)
+
+
 def _current_stream_ptr(tensor):
+    if _is_native(tensor):
+        return 0                                  # the device's default stream
     import torch
     return torch.cuda.current_stream(tensor.device).cuda_stream if tensor.is_cuda else 0
 
 
+def _is_f64(array):
+    if _is_native(array):
+        return array.dtype == np.float64
+    import torch
+    return array.dtype == torch.float64
+
+
 def _dtype_code(tensor):
-    """ZK_F32 / ZK_F64 of a torch tensor; anything else is an error (the kernels would read it as float64)."""
+    """ZK_F32 / ZK_F64 of a torch tensor or DeviceArray; anything else is an error (the kernels would read it as float64)."""
+    if _is_native(tensor):
+        if tensor.dtype == np.float32:
+            return _native.ZK_F32
+        if tensor.dtype == np.float64:
+            return _native.ZK_F64
+        raise TypeError(f"the device entry points take float32 or float64 arrays, not {tensor.dtype}; convert first "
+                        "(ZPs.transform does that for NumPy input)")
     import torch
     if tensor.dtype == torch.float32:
         return _native.ZK_F32
@@ -100,12 +129,11 @@ def _check_operand(plan, tensor, what):
 def patch_moments_device(plan: "_native.Plan", patches, out=None):
     """Run the batch kernel on a CUDA/HIP torch tensor ``(N, K, K)`` (float32/float64) on torch's
     current stream; returns the ``(N, n_poly)`` float64 tensor (no host copies)."""
-    import torch
     _check_operand(plan, patches, "patches")
     code = _dtype_code(patches)
     n = patches.shape[0]
     if out is None:
-        out = torch.empty((n, plan.n_poly), dtype=torch.float64, device=patches.device)
+        out = _empty_like((n, plan.n_poly), patches)
     else:
         _check_operand(plan, out, "out")
     plan.transform_patches_dev(patches.data_ptr(), code, n, out.data_ptr(), _current_stream_ptr(patches))
@@ -116,7 +144,6 @@ def frame_moments_device(plan: "_native.Plan", image, row0=0, n_rows=None, out=N
     """Run the dense kernel for output rows ``[row0, row0+n_rows)`` of a CUDA/HIP torch frame ``(H, W)``.
     Returns ``(n_poly, n_rows, W)`` float64 -- or, with ``full`` (an ``(n_poly, H, W)`` tensor), writes the
     band in place into it and returns ``full``."""
-    import torch
     _check_operand(plan, image, "image")
     code = _dtype_code(image)
     h, w = image.shape
@@ -124,12 +151,12 @@ def frame_moments_device(plan: "_native.Plan", image, row0=0, n_rows=None, out=N
     stream = _current_stream_ptr(image)
     if full is not None:
         _check_operand(plan, full, "full")
-        assert tuple(full.shape) == (plan.n_poly, h, w) and full.dtype == torch.float64
+        assert tuple(full.shape) == (plan.n_poly, h, w) and _is_f64(full)
         plan.transform_frame_dev(image.data_ptr(), code, h, w, row0, n_rows, full.data_ptr() + row0 * w * 8, stream,
                                  plane_stride=h * w)
         return full
     if out is None:
-        out = torch.empty((plan.n_poly, n_rows, w), dtype=torch.float64, device=image.device)
+        out = _empty_like((plan.n_poly, n_rows, w), image)
     else:
         _check_operand(plan, out, "out")
     plan.transform_frame_dev(image.data_ptr(), code, h, w, row0, n_rows, out.data_ptr(), stream)
@@ -143,7 +170,6 @@ def frame_maps_device(plan: "_native.Plan", image, n_complex, folds=(2, 3, 4, 6)
     ``(n_complex, n_rows, W)``, ``(n_rows, W)`` (``None`` for outputs not requested).  With
     ``full = (rot_full, abs_full, mirror_full)`` (whole-frame tensors, entries ``None`` where not wanted) the
     band is written in place into them and ``full`` is returned."""
-    import torch
     _check_operand(plan, image, "image")
     code = _dtype_code(image)
     h, w = image.shape
@@ -155,10 +181,10 @@ def frame_maps_device(plan: "_native.Plan", image, n_complex, folds=(2, 3, 4, 6)
                             m_unselect, p, theta if full[2] is not None else None, ptr(full[0]), ptr(full[1]),
                             ptr(full[2]), stream, plane_stride=h * w)
         return full
-    mk = lambda planes: torch.empty((planes, n_rows, w), dtype=torch.float64, device=image.device)
+    mk = lambda planes: _empty_like((planes, n_rows, w), image)
     rot = mk(len(folds)) if folds is not None and len(folds) else None
     ab = mk(n_complex) if want_abs else None
-    mir = torch.empty((n_rows, w), dtype=torch.float64, device=image.device) if theta is not None else None
+    mir = _empty_like((n_rows, w), image) if theta is not None else None
     ptr = lambda t: t.data_ptr() if t is not None else 0
     plan.frame_maps_dev(image.data_ptr(), code, h, w, row0, n_rows, folds, m_unselect, p, theta,
                         ptr(rot), ptr(ab), ptr(mir), stream)
@@ -303,8 +329,7 @@ class DeviceCompute:
         self.plan, self.n_poly = plan, plan.n_poly
 
     def empty(self, shape, like):
-        import torch
-        return torch.empty(shape, dtype=torch.float64, device=like.device)
+        return _empty_like(shape, like)
 
     def stream(self, tensor):
         return _current_stream_ptr(tensor)
