@@ -58,9 +58,12 @@ extern "C" {
 #define ZK_E_COMM     (-10004)  /* RCCL unavailable, rendezvous failed or a collective returned an error */
 #define ZK_E_FFT      (-10005)  /* hipFFT unavailable or a transform failed */
 
-/* kernel selection, for tests and A/B measurements (default ZK_PATH_AUTO = best available) */
+/* kernel selection, for tests and A/B measurements.  Default ZK_PATH_AUTO = the fastest family that restates the reference
+ * to SURVEY 8c's criterion (elementwise rtol 1e-6, floor 1e-12 max|Z| up to n_max 12, 1e-11 above) on the reference's own
+ * outputs: the polynomial kernels (SEPARABLE / STREAM) for full Zernike sets up to n_max 16, the plain sum on the matrix
+ * cores (DIRECT) from n_max 17 and for every other set of >= 92 functions, else FOLDED / GENERIC. */
 #define ZK_PATH_AUTO      0
-#define ZK_PATH_GENERIC   1  /* any size / n_max / dtype: unfolded direct summation, ~1e-16 of the definition */
+#define ZK_PATH_GENERIC   1  /* any size / n_max / dtype: unfolded direct summation, one output per lane, ~1e-16 of the definition */
 #define ZK_PATH_FOLDED    2  /* frame only: mirror-folded direct summation (4x fewer FMAs), ~1e-15            */
 #define ZK_PATH_SEPARABLE 3  /* mirror-folded row-separable sums (Legendre products), ~1e-13; fastest.  Full
                                 Zernike sets up to n_max 24 (17-24: one pass per mirror-parity class; ~1e-9 at 20, ~3e-8 at 24,
@@ -68,6 +71,13 @@ extern "C" {
 #define ZK_PATH_STREAM    4  /* patches only: row-separable sums over the contiguous pixel stream of a patch,
                                 whole 128-B lines whatever the patch size; AUTO prefers it where the row-pair
                                 kernel of ZK_PATH_SEPARABLE would issue half-line requests */
+#define ZK_PATH_DIRECT    5  /* sets of >= 92 functions (n_max >= 13), windows of 16 .. 512 px: the plain sum over the CALLER'S
+                                basis values as a float64 GEMM on the matrix cores (v_mfma_f64_16x16x4_f64) -- the reference's
+                                own arithmetic (np.dot, _zps.py:155), ~1e-15, at any order.  Dense mode multiplies window pixel
+                                (r, c) with (-1)^n V(K-1-r, K-1-c), which is what the reference's convolution + sign fix does
+                                (_zps.py:165-178; equal to V(r, c) for an exactly point-symmetric basis), whenever the set is
+                                point-symmetric to 1e-6.  SEPARABLE stays available as an explicit opt-in above n_max 16:
+                                2-6x faster, ~1e-10 (n_max 20) .. 1e-9 (n_max 24) of max|Z| from the reference's result */
 
 typedef struct zk_plan zk_plan;
 
@@ -101,6 +111,9 @@ int zk_plan_has_path(const zk_plan* plan, int mode, int dtype, int path);
 int zk_plan_supports(const zk_plan* plan, int op, int dtype);
 /* Number of pixels inside the unit disk (rho <= 1 as evaluated by the caller's basis). */
 int zk_plan_disk_pixels(const zk_plan* plan);
+/* The family (ZK_PATH_*, never AUTO) a transform of `n_units` patches (mode 0) / of a frame (mode 1) would run on with the
+ * plan's current setting: what ZK_PATH_AUTO resolves to, or the forced path; -1 if a forced path is unavailable. */
+int zk_plan_resolved_path(const zk_plan* plan, int mode, int dtype, int64_t n_units);
 /* Force a kernel family (ZK_PATH_*); a forced path that is unavailable makes transforms fail. */
 int zk_plan_set_path(zk_plan* plan, int path);
 
@@ -119,8 +132,13 @@ int zk_transform_patches_dev(zk_plan* plan, const void* patches_dev, int dtype,
 
 /*
  * Dense frame (reference _zps.py:159-193, i.e. fftconvolve(mode='same') * (-1)^n / area):
- *   out[j, i, k] = sum_{r,c} pad(image)[i - ea + r, k - ea + c] * basis[j, r, c] / (pi size^2/4)
- *   with eb = (size-1)/2, ea = size-1-eb and zero padding outside the image.
+ *   out[j, i, k] = (-1)^n[j] * sum_{r,c} pad(image)[i - ea + r, k - ea + c] * basis[j, size-1-r, size-1-c] / (pi size^2/4)
+ *   with eb = (size-1)/2, ea = size-1-eb and zero padding outside the image -- the convolution and the sign fix
+ *   of the reference written out.  For a point-symmetric basis (V(-x, -y) = (-1)^n V(x, y): every Zernike set in exact
+ *   arithmetic) this is the inner product of the window with basis[j]; the reference's float64 basis is point-symmetric
+ *   only up to rounding (1e-13 of max|V| at n_max 10, 1e-8 at 24, 8e-4 at 36), and the kernels that sum the caller's own
+ *   numbers (ZK_PATH_GENERIC, ZK_PATH_DIRECT) follow the formula above to the letter; the polynomial kernels
+ *   (ZK_PATH_SEPARABLE / FOLDED, verified Zernike sets only) evaluate the exactly symmetric polynomial.
  *   image : (H, W) of `dtype`;  out : (n_poly, H, W) float64 (moment-major, as the reference).
  * The *_dev variant computes output rows [row0, row0+n_rows) only and writes them to
  * out_dev laid out as (n_poly, n_rows, W) -- the row-band shard of one GPU; the image operand

@@ -128,6 +128,12 @@ static int build_generic_tables(zk_plan* p, const double* basis) {
       tab[((size_t)c * p->npx + t) * CH + l] =
           basis[((size_t)j * K + pix[t].x) * K + pix[t].y] * inv_area;
   }
+  // dense mode of the kernels that sum the caller's own numbers follows the reference's convolution (zk_plan::conv_flip)
+  p->conv_flip = !getenv("ZK_NO_CONV_FLIP");
+  std::vector<double> sign((size_t)p->n_chunks * CH, 1.0);
+  for (int j = 0; j < NP; ++j) sign[j] = (p->conv_flip && (p->n[j] & 1)) ? -1.0 : 1.0;
+  ZK_HIP(hipMalloc((void**)&p->d_sign, sign.size() * sizeof(double)));
+  ZK_HIP(hipMemcpy(p->d_sign, sign.data(), sign.size() * sizeof(double), hipMemcpyHostToDevice));
   if (p->npx == 0) return 0;
   ZK_HIP(hipMalloc((void**)&p->d_pix, pix.size() * sizeof(int2)));
   ZK_HIP(hipMemcpy(p->d_pix, pix.data(), pix.size() * sizeof(int2), hipMemcpyHostToDevice));
@@ -148,6 +154,7 @@ extern "C" void zk_plan_destroy(zk_plan* p) {
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   if (p->d_pix) (void)hipFree(p->d_pix);
   if (p->d_gen_tab) (void)hipFree(p->d_gen_tab);
+  if (p->d_sign) (void)hipFree(p->d_sign);
   zk_host_release(p);
   if (p->d_scratch) (void)hipFree(p->d_scratch);
   if (p->d_gather) (void)hipFree(p->d_gather);
@@ -188,7 +195,13 @@ extern "C" int zk_plan_create(int size, int n_poly, const int32_t* n, const int3
   if (!rc) rc = build_generic_tables(p, basis);
   if (!rc) rc = zk_fold_build(p, basis);
   if (!rc) rc = zk_sep_build(p, basis);
-  if (!rc && !p->sep) rc = zk_direct_build(p, basis);  // large sets the polynomial kernels do not take (n_max > 24)
+  if (!rc) rc = zk_direct_build(p, basis);  // the plain sum on the matrix cores: sets of >= 92 functions (n_max >= 13)
+  if (!rc) {
+    // From which order ZK_PATH_AUTO leaves the polynomial kernels for the plain sum (see resolve_path); ZK_AUTO_DIRECT_NMAX
+    // in the environment moves the switch for A/B measurements.
+    const char* env = getenv("ZK_AUTO_DIRECT_NMAX");
+    p->auto_direct_from = env && *env ? atoi(env) : ZK_AUTO_DIRECT_NMAX_DEFAULT;
+  }
   if (rc) {
     std::string keep = g_last_error;
     zk_plan_destroy(p);
@@ -205,14 +218,30 @@ static bool path_available(const zk_plan* p, int mode, int dtype, int path) {
     case ZK_PATH_FOLDED: return mode == 1 && zk_fast_frame_available(p, dtype);
     case ZK_PATH_SEPARABLE: return mode == 0 ? zk_sep_patches_available(p, dtype) : zk_sep_frame_available(p, dtype);
     case ZK_PATH_STREAM: return mode == 0 && zk_sep_stream_available(p, dtype);
+    case ZK_PATH_DIRECT: return mode == 0 ? zk_direct_patches_available(p, dtype) : zk_direct_frame_available(p, dtype);
   }
   return false;
+}
+
+// Does ZK_PATH_AUTO take the plain sum over the caller's own numbers (matrix cores) for this plan?  Yes for every large
+// set without polynomial tables (n_max > 24, other sets), and for the full Zernike sets from order `auto_direct_from`:
+// the polynomial kernels substitute the exact polynomial for the caller's values and recombine Legendre sums whose
+// coefficients grow like (1 + sqrt 2)^n, so their distance from the reference's np.dot grows with the order -- measured
+// against reference outputs on structured inputs (tests/golden: st_*), profiles/r04_high_orders.txt -- while the plain
+// sum is the reference's own arithmetic at every order.
+bool zk_plan_auto_direct(const zk_plan* p, int mode, int dtype) {
+  if (!path_available(p, mode, dtype, ZK_PATH_DIRECT)) return false;
+  if (!p->sep) return true;
+  const int n_max = zk_full_set_nmax(p);
+  return n_max >= p->auto_direct_from;
 }
 
 // ZK_PATH_AUTO: separable (batches: its stream form where the plan prefers it), else folded (frame), else generic.
 // `n_units` = patches of the call (batch mode).
 static int resolve_path(const zk_plan* p, int mode, int dtype, int64_t n_units = 0) {
   if (p->path != ZK_PATH_AUTO) return path_available(p, mode, dtype, p->path) ? p->path : -1;
+  if (zk_plan_auto_direct(p, mode, dtype) && !getenv("ZK_NO_DIRECT"))
+    return mode == 1 || n_units >= 64 ? ZK_PATH_DIRECT : ZK_PATH_GENERIC;  // (less than a wave of patches: the per-lane sum)
   if (mode == 0 && path_available(p, mode, dtype, ZK_PATH_STREAM) &&
       (zk_sep_stream_preferred(p, dtype, n_units) || !path_available(p, mode, dtype, ZK_PATH_SEPARABLE)))
     return ZK_PATH_STREAM;
@@ -224,6 +253,11 @@ static int resolve_path(const zk_plan* p, int mode, int dtype, int64_t n_units =
 extern "C" int zk_plan_has_path(const zk_plan* p, int mode, int dtype, int path) {
   if (!p || (dtype != ZK_F32 && dtype != ZK_F64)) return 0;
   return (int)path_available(p, mode, dtype, path);
+}
+
+extern "C" int zk_plan_resolved_path(const zk_plan* p, int mode, int dtype, int64_t n_units) {
+  if (!p || (dtype != ZK_F32 && dtype != ZK_F64) || (mode != 0 && mode != 1)) return -1;
+  return resolve_path(p, mode, dtype, n_units);
 }
 
 extern "C" int zk_plan_supports(const zk_plan* p, int op, int dtype) {
@@ -238,7 +272,7 @@ extern "C" int zk_plan_supports(const zk_plan* p, int op, int dtype) {
 extern "C" int zk_plan_disk_pixels(const zk_plan* p) { return p ? p->npx : 0; }
 
 extern "C" int zk_plan_set_path(zk_plan* p, int path) {
-  if (!p || path < ZK_PATH_AUTO || path > ZK_PATH_STREAM) return zk_fail(ZK_E_BADARG, "bad path");
+  if (!p || path < ZK_PATH_AUTO || path > ZK_PATH_DIRECT) return zk_fail(ZK_E_BADARG, "bad path");
   p->path = path;
   return 0;
 }
@@ -267,9 +301,9 @@ extern "C" int zk_transform_patches_dev(zk_plan* p, const void* patches, int dty
   if (path < 0) return zk_fail(ZK_E_BADARG, "the forced kernel path is not available for this plan / dtype");
   if (path == ZK_PATH_SEPARABLE) return zk_launch_sep_patches(p, patches, dtype, n_patches, out, s);
   if (path == ZK_PATH_STREAM) return zk_launch_sep_stream(p, patches, dtype, n_patches, out, s);
-  // the plain sum over the caller's numbers: DMA-staged form for large sets (ZK_NO_DIRECT keeps the per-lane loads: A/B, tests)
-  if (zk_direct_patches_available(p, dtype) && n_patches >= 64 && !getenv("ZK_NO_DIRECT"))
-    return zk_launch_direct_patches(p, patches, dtype, n_patches, out, s);
+  // the plain sum over the caller's numbers on the matrix cores (ZK_PATH_AUTO: resolve_path; ZK_NO_DIRECT in the environment
+  // keeps AUTO off it); a forced ZK_PATH_GENERIC is always the per-lane kernel
+  if (path == ZK_PATH_DIRECT) return zk_launch_direct_patches(p, patches, dtype, n_patches, out, s);
   return zk_launch_generic_patches(p, patches, dtype, n_patches, out, s);
 }
 
@@ -292,8 +326,7 @@ extern "C" int zk_transform_frame_dev(zk_plan* p, const void* image, int dtype, 
     return zk_launch_sep_strip(p, image, dtype, H, W, row0, n_rows, out, s);
   if (path == ZK_PATH_SEPARABLE) return zk_launch_sep_frame(p, image, dtype, H, W, row0, n_rows, out, s);
   if (path == ZK_PATH_FOLDED) return zk_launch_fast_frame(p, image, dtype, H, W, row0, n_rows, out, s);
-  if (zk_direct_frame_available(p, dtype) && !getenv("ZK_NO_DIRECT"))  // large sets: the same plain sum on the matrix cores
-    return zk_launch_direct_frame(p, image, dtype, H, W, row0, n_rows, out, s);
+  if (path == ZK_PATH_DIRECT) return zk_launch_direct_frame(p, image, dtype, H, W, row0, n_rows, out, s);
   return zk_launch_generic_frame(p, image, dtype, H, W, row0, n_rows, out, s);
 }
 

@@ -35,7 +35,9 @@
 struct zk_direct_unit {
   int32_t run_off[4];  // byte offsets of the unit's four runs inside a patch
   int32_t steps;       // bit s: step s (4 pixel slots) has a non-zero table row
-  int32_t pad[3];
+  uint32_t own[2];     // bit 4 s + k: slot k of step s stands for a disk pixel (the others contribute an exact zero, whatever
+                       // the pixel holds: a NaN outside the disk, or in the overlap of two runs, never reaches a moment)
+  int32_t pad;
 };
 
 struct zk_direct_tables {
@@ -48,7 +50,9 @@ struct zk_direct_tables {
   // dense mode: the disk rows in pieces of 4 consecutive pixels (a piece = one MFMA step)
   int n_steps = 0;
   int tile_pitch = 0;
-  int32_t* d_step_off = nullptr;  // [n_steps] tile element offset of the piece's first pixel (window row r: r * tile_pitch + c)
+  bool flipped = false;           // the dense table holds (-1)^n V(K-1-r, K-1-c): what the reference's convolution multiplies
+  int32_t* d_step_off = nullptr;  // [n_steps] bits 0..23: tile element offset of the piece's first pixel (window row r:
+                                  // r * tile_pitch + c); bits 24..27: which of its 4 slots stand for a disk pixel
   double* d_ftab = nullptr;       // [n_chunks][n_steps][4][CH]
 };
 
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __re
   issue(0);
   for (int u = 0; u < n_units; ++u) {
     const int steps = utab[8 * u + 4];
+    const unsigned own_lo = (unsigned)utab[8 * u + 5], own_hi = (unsigned)utab[8 * u + 6];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of unit u has landed
     const double* __restrict__ tu = tlane + (size_t)u * (4 * UP) * CH;
 #pragma unroll 2
@@ -138,8 +143,12 @@ __global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __re
       const int x = 4 * (st % PXG) + kr;                             // slot inside the run
       const int gsl = ((x / PXG + prot) & 3) * PXG + x % PXG;        // its element inside the patch's (rotated) 64 B
       double av[4], bv[FB];
+      const bool mine = (((st < 8 ? own_lo : own_hi) >> (4 * (st & 7) + kr)) & 1u) != 0;
 #pragma unroll
-      for (int pb = 0; pb < 4; ++pb) av[pb] = (double)ws[rho * 64 * UP + pbase[pb] + gsl];
+      for (int pb = 0; pb < 4; ++pb) {
+        const double v = (double)ws[rho * 64 * UP + pbase[pb] + gsl];
+        av[pb] = mine ? v : 0.0;
+      }
       const double* __restrict__ tr = tu + (size_t)st * 4 * CH;
 #pragma unroll
       for (int fb = 0; fb < FB; ++fb) bv[fb] = tr[16 * fb];
@@ -240,10 +249,15 @@ __global__ __launch_bounds__(512) void zk_frame_direct_kernel(const TIN* __restr
       for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = v4d{0.0, 0.0, 0.0, 0.0};
     const double* __restrict__ tl = tab + ((size_t)ch * n_steps * 4 + kr) * CH + li;
     for (int st = 0; st < n_steps; ++st) {
-      const TIN* __restrict__ px = mine + soff[st];
+      const int so = soff[st];
+      const TIN* __restrict__ px = mine + (so & 0xffffff);
+      const bool own = ((so >> (24 + kr)) & 1) != 0;
       double av[4], bv[FB];
 #pragma unroll
-      for (int pb = 0; pb < 4; ++pb) av[pb] = (double)px[16 * pb];
+      for (int pb = 0; pb < 4; ++pb) {
+        const double v = (double)px[16 * pb];
+        av[pb] = own ? v : 0.0;
+      }
       const double* __restrict__ tr = tl + (size_t)st * 4 * CH;
 #pragma unroll
       for (int fb = 0; fb < FB; ++fb) bv[fb] = tr[16 * fb];
@@ -308,7 +322,7 @@ void zk_direct_free(zk_plan* p) {
 // its zero pattern -- a table row holds the caller's values (/ area) of one pixel for the CH functions of a chunk.
 int zk_direct_build(zk_plan* p, const double* basis) {
   const int K = p->size, NP = p->n_poly;
-  if (NP < 128 || NP > 1024 || K < 16 || K > 512) return 0;
+  if (NP < 92 || NP > 1024 || K < 16 || K > 512) return 0;
   const double inv_area = 1.0 / (M_PI * (double)K * (double)K / 4.0);
   std::vector<char> act((size_t)K * K, 0);
   for (int j = 0; j < NP; ++j)
@@ -359,7 +373,10 @@ int zk_direct_build(zk_plan* p, const double* basis) {
       for (int rho = 0; rho < 4; ++rho) un.run_off[rho] = run_off[4 * u + rho];
       for (int st = 0; st < slots / 4; ++st)
         for (int k = 0; k < 4; ++k)
-          if (owner[(size_t)u * slots + 4 * st + k] >= 0) un.steps |= 1 << st;
+          if (owner[(size_t)u * slots + 4 * st + k] >= 0) {
+            un.steps |= 1 << st;
+            un.own[st >> 3] |= 1u << (4 * (st & 7) + k);
+          }
     }
     zk_direct_tables::per_type& t = d->t[dt];
     t.n_units = n_units;
@@ -374,27 +391,42 @@ int zk_direct_build(zk_plan* p, const double* basis) {
     if (!rc) rc = upload(&t.d_tab, tab);
     if (rc) return rc;
   }
-  // ---- dense mode: disk rows in pieces of 4 consecutive pixels (the tile row has 63 spare columns: a piece may run past the
-  // window's last column, its extra slots own nothing)
+  // ---- dense mode: disk rows in pieces of 4 consecutive pixels.  A piece may run up to 3 pixels past the window's last
+  // column (its extra slots own nothing and are masked), so position 63 of a workgroup reads up to column K + 65 of the tile.
+  // What the reference's dense path multiplies a window pixel (r, c) with is not V(r, c) but (-1)^n V(K-1-r, K-1-c)
+  // (_zps.py:165-178: a convolution, then the sign): the dense table holds the flipped, signed values whenever the plan
+  // says so (zk_plan::conv_flip).
   {
-    d->tile_pitch = K + 63;
+    d->tile_pitch = K + 66;
+    d->flipped = p->conv_flip;
+    auto value = [&](int j, int px) {
+      if (!d->flipped) return basis[(size_t)j * K * K + px];
+      return ((p->n[j] & 1) ? -1.0 : 1.0) * basis[(size_t)j * K * K + (K * K - 1 - px)];
+    };
+    std::vector<char> actd((size_t)K * K);  // window pixels the dense table has a non-zero row for
+    for (int t = 0; t < K * K; ++t) actd[t] = d->flipped ? act[K * K - 1 - t] : act[t];
     std::vector<int32_t> soff;
     std::vector<int> owner;  // [step][4]
     for (int r = 0; r < K; ++r)
       for (int c = 0; c < K;) {
-        if (!act[(size_t)r * K + c]) {
+        if (!actd[(size_t)r * K + c]) {
           ++c;
           continue;
         }
-        soff.push_back(r * d->tile_pitch + c);
-        for (int k = 0; k < 4; ++k) owner.push_back(c + k < K && act[(size_t)r * K + c + k] ? r * K + c + k : -1);
+        int packed = r * d->tile_pitch + c;
+        for (int k = 0; k < 4; ++k) {
+          const bool own = c + k < K && actd[(size_t)r * K + c + k];
+          owner.push_back(own ? r * K + c + k : -1);
+          if (own) packed |= 1 << (24 + k);
+        }
+        soff.push_back(packed);
         c += 4;
       }
     std::vector<int> cover((size_t)K * K, 0);
     for (int o : owner)
       if (o >= 0) ++cover[o];
     for (int t = 0; t < K * K; ++t)
-      if (cover[t] != (act[t] ? 1 : 0)) {
+      if (cover[t] != (actd[t] ? 1 : 0)) {
         zk_direct_free(p);
         return zk_fail(ZK_E_BADARG, "internal: direct dense pieces do not tile the disk");
       }
@@ -404,7 +436,7 @@ int zk_direct_build(zk_plan* p, const double* basis) {
       for (size_t k = 0; k < owner.size(); ++k) {
         if (owner[k] < 0) continue;
         double* dst = &ftab[((size_t)c * owner.size() + k) * CH];
-        for (int i = 0; i < CH && c * CH + i < NP; ++i) dst[i] = basis[(size_t)(c * CH + i) * K * K + owner[k]] * inv_area;
+        for (int i = 0; i < CH && c * CH + i < NP; ++i) dst[i] = value(c * CH + i, owner[k]) * inv_area;
       }
     int rc = upload(&d->d_step_off, soff);
     if (!rc) rc = upload(&d->d_ftab, ftab);

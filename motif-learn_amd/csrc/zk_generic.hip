@@ -10,7 +10,9 @@
 // folded kernels (zk_fast_*.hip) do not cover, not the measured hot path.
 //
 // Arithmetic: out = sum_t pixel(t) * (basis[j][t] / area), accumulated in float64 in disk
-// order -- the definition both reference paths approximate (_zps.py:155, :165-178).
+// order -- the definition both reference paths approximate (_zps.py:155, :165-178).  Dense mode of a
+// point-symmetric set (zk_plan::conv_flip) pairs the table rows with the window the way the reference's
+// convolution does: pixel (K-1-r, K-1-c) with row (r, c), times (-1)^n.
 #include "zk_internal.h"
 
 #ifndef ZK_GEN_PB
@@ -24,7 +26,7 @@ template <typename T, int MODE, int CHUNK>  // MODE 0: batch of patches, 1: dens
 __global__ __launch_bounds__(256) void zk_generic_kernel(
     const T* __restrict__ in, double* __restrict__ out, const int2* __restrict__ pix,
     const double* __restrict__ tab, int npx, int n_poly, int n_chunks, int size, long long n_units,
-    int H, int W, int row0, long long plane) {
+    int H, int W, int row0, long long plane, const double* __restrict__ sign, int flip) {
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool live = u < n_units;
   const int ea = size - 1 - (size - 1) / 2;
@@ -58,8 +60,10 @@ __global__ __launch_bounds__(256) void zk_generic_kernel(
         const int t = t0 + q < npx ? t0 + q : npx - 1;  // (wave-uniform) past the end: the last pixel again, weighted 0 below
         const int rcx = cpix[2 * t], rcy = cpix[2 * t + 1];
         if (MODE == 1) {
-          const int ii = oi - ea + rcx;
-          const int kk = ok - ea + rcy;
+          // (flip: the reference's dense path is a convolution -- table row (r, c) meets window pixel (K-1-r, K-1-c), the
+          //  (-1)^n of _zps.py:173-178 is applied at the store; zk_plan::conv_flip)
+          const int ii = oi - ea + (flip ? size - 1 - rcx : rcx);
+          const int kk = ok - ea + (flip ? size - 1 - rcy : rcy);
           const bool inside = live && ii >= 0 && ii < H && kk >= 0 && kk < W && t0 + q < npx;
           f[q] = inside ? (double)in[(long long)ii * W + kk] : 0.0;
         } else {
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void zk_generic_kernel(
         if (jj < n_poly) {
           if (MODE == 1) {
             // (n_poly, n_rows, W): u already enumerates (row, col) of the band
-            out[(long long)jj * plane + u] = acc[j];
+            out[(long long)jj * plane + u] = acc[j] * ((const ZK_TAB double*)sign)[jj];
           } else {
             out[u * n_poly + jj] = acc[j];
           }
@@ -117,7 +121,8 @@ int launch(zk_plan* p, const void* in, int dtype, long long n_units, int H, int 
   if (rc) return rc;
 #define ZK_GEN_LAUNCH(T, CH)                                                                              \
   hipLaunchKernelGGL((zk_generic_kernel<T, MODE, CH>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)in, out, \
-                     p->d_pix, p->d_gen_tab, p->npx, p->n_poly, p->n_chunks, p->size, n_units, H, W, row0, plane)
+                     p->d_pix, p->d_gen_tab, p->npx, p->n_poly, p->n_chunks, p->size, n_units, H, W, row0, plane, \
+                     p->d_sign, (int)(MODE == 1 && p->conv_flip))
   if (dtype == ZK_F32) {
     if (p->gen_chunk == 64) ZK_GEN_LAUNCH(float, 64);
     else ZK_GEN_LAUNCH(float, 32);

@@ -35,6 +35,13 @@ struct zk_plan {
   int n_chunks = 0;              // ceil(n_poly / gen_chunk)
   int2* d_pix = nullptr;         // [npx] (row, col) of each disk pixel, row-major order
   double* d_gen_tab = nullptr;   // [n_chunks][npx][gen_chunk], basis/area, zero padded
+  // Dense mode restates the reference's CONVOLUTION + sign fix (_zps.py:165-178): window pixel (r, c) meets
+  // (-1)^n V(K-1-r, K-1-c) -- equal to V(r, c) only for an exactly point-symmetric basis, and the reference's float64 basis
+  // is that to 1e-13 (n_max 10) .. 1e-8 (24) .. 8e-4 (36) of max|V|.  The kernels that sum the caller's own numbers
+  // (generic, direct) therefore take them flipped and signed in dense mode (ZK_NO_CONV_FLIP in the environment: the plain
+  // inner product, for A/B); the polynomial kernels evaluate the exactly symmetric polynomial either way.
+  bool conv_flip = false;
+  double* d_sign = nullptr;      // [n_chunks * gen_chunk] (-1)^n per function (1 without conv_flip and past n_poly)
 
   // ---- parity-folded tables (fast kernels) ----------------------------------------
   zk_fold_tables* fold = nullptr;  // nullptr when the basis lacks the mirror parities
@@ -43,7 +50,8 @@ struct zk_plan {
   zk_sep_tables* sep = nullptr;    // nullptr when the basis is not the standard polynomial set
 
   // ---- large sets, batch mode: DMA-staged direct sums, CH functions per launch (zk_direct_patches.hip) ----
-  struct zk_direct_tables* direct = nullptr;  // nullptr below 128 functions
+  struct zk_direct_tables* direct = nullptr;  // nullptr below 92 functions
+  int auto_direct_from = 1 << 30;             // full Zernike sets: ZK_PATH_AUTO takes the plain sum from this n_max on
 
   // ---- symmetry maps: fold weights + cos / sin(m theta) (zk_sep_maps.hip).  One device table per distinct
   // (folds, m_unselect, theta) option set, kept for the life of the plan (a few KiB each, at most
@@ -169,6 +177,10 @@ bool zk_sep_patches_available(const zk_plan* p, int dtype);
 int zk_direct_build(zk_plan* p, const double* basis);  // zk_direct_patches.hip
 void zk_direct_free(zk_plan* p);
 bool zk_direct_patches_available(const zk_plan* p, int dtype);
+bool zk_plan_auto_direct(const zk_plan* p, int mode, int dtype);  // zk_api.hip: does ZK_PATH_AUTO take the plain sum?
+#ifndef ZK_AUTO_DIRECT_NMAX_DEFAULT
+#define ZK_AUTO_DIRECT_NMAX_DEFAULT 17
+#endif
 int zk_launch_direct_patches(zk_plan* p, const void* in, int dtype, int64_t n_patches, double* out, hipStream_t s);
 bool zk_direct_frame_available(const zk_plan* p, int dtype);
 int zk_launch_direct_frame(zk_plan* p, const void* in, int dtype, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out,

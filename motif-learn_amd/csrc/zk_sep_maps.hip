@@ -16,6 +16,8 @@
 // read again by a separate map pass.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "zk_sep.h"
 
 // Build groups: the kernel instances are spread over several translation units (Makefile) so that they
@@ -477,7 +479,7 @@ int zk_maps_planes_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t 
   // (bands of <= 1 GiB of moments: smaller bands mean more launches of five under-filled kernels each -- 2048^2 at (48, 20):
   //  28.8 ms with 1-GiB bands, 45 ms at 256 MiB, 187 ms at 32 MiB)
   int64_t band = (int64_t)((size_t)1 << 30) / ((int64_t)p->n_poly * W * (int64_t)sizeof(double));
-  band = band < 4 ? 4 : (band > n_rows ? n_rows : band);
+  band = band < 8 ? 8 : (band > n_rows ? n_rows : band);
   const size_t need = (size_t)p->n_poly * band * W * sizeof(double);
   if (p->d_scratch_bytes < need) {
     if (p->d_scratch) ZK_HIP(hipFree(p->d_scratch));
@@ -491,7 +493,11 @@ int zk_maps_planes_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t 
     const int64_t nb = n_rows - b0 < band ? n_rows - b0 : band;
     const long long keep = p->out_plane;
     p->out_plane = 0;  // the scratch matrix is compact
-    int rc = zk_launch_sep_frame(p, in, dtype, H, W, row0 + b0, nb, p->d_scratch, s);
+    // the band's moments from the kernel family ZK_PATH_AUTO takes at this order (zk_api.hip: the plain sum on the matrix
+    // cores where the polynomial kernels miss the parity criterion), unless the separable family is forced
+    const bool direct = p->path != ZK_PATH_SEPARABLE && zk_plan_auto_direct(p, 1, dtype) && !getenv("ZK_NO_DIRECT");
+    int rc = direct ? zk_launch_direct_frame(p, in, dtype, H, W, row0 + b0, nb, p->d_scratch, s)
+                    : zk_launch_sep_frame(p, in, dtype, H, W, row0 + b0, nb, p->d_scratch, s);
     p->out_plane = keep;
     if (rc) return rc;
     if ((rc = zk_prof_begin(p, s))) return rc;

@@ -16,12 +16,13 @@ import numpy as np
 
 ZK_F32, ZK_F64 = 0, 1
 ZK_U8, ZK_U16, ZK_I16 = 2, 3, 4   # host-buffer entry points only: widened to float32 on the device (exact)
-PATH_AUTO, PATH_GENERIC, PATH_FOLDED, PATH_SEPARABLE, PATH_STREAM = 0, 1, 2, 3, 4
+PATH_AUTO, PATH_GENERIC, PATH_FOLDED, PATH_SEPARABLE, PATH_STREAM, PATH_DIRECT = 0, 1, 2, 3, 4, 5
 OP_POINTS, OP_MAPS = 1, 2
 XFER_SEND, XFER_RECV, XFER_ALLGATHER, XFER_BCAST = 1, 2, 3, 4
 COMM_AUTO, COMM_P2P, COMM_ALLGATHER, COMM_BCAST = 0, 1, 2, 3
 COMM_ALGOS = {"": COMM_AUTO, "auto": COMM_AUTO, "p2p": COMM_P2P, "allgather": COMM_ALLGATHER, "bcast": COMM_BCAST}
-PATH_NAMES = {PATH_GENERIC: "generic", PATH_FOLDED: "folded", PATH_SEPARABLE: "separable", PATH_STREAM: "stream"}
+PATH_NAMES = {PATH_GENERIC: "generic", PATH_FOLDED: "folded", PATH_SEPARABLE: "separable", PATH_STREAM: "stream",
+              PATH_DIRECT: "direct"}
 
 
 
@@ -44,6 +45,7 @@ SYMBOLS = {
                                c_int, POINTER(c_void_p)]),
     "zk_plan_destroy": (None, [c_void_p]),
     "zk_plan_has_path": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "zk_plan_resolved_path": (c_int, [c_void_p, c_int, c_int, c_int64]),
     "zk_plan_supports": (c_int, [c_void_p, c_int, c_int]),
     "zk_plan_disk_pixels": (c_int, [c_void_p]),
     "zk_plan_set_path": (c_int, [c_void_p, c_int]),
@@ -314,10 +316,10 @@ class Plan:
         """True if the plan has the key-point (OP_POINTS) / fused-maps (OP_MAPS) kernel for the element type."""
         return bool(self._lib.zk_plan_supports(self._h, op, dtype_code_))
 
-    def best_path(self, mode, dtype_code_):
-        for path in (PATH_SEPARABLE, PATH_STREAM, PATH_FOLDED, PATH_GENERIC):
-            if self.has_path(mode, dtype_code_, path):
-                return path
+    def best_path(self, mode, dtype_code_, n_units=1 << 20):
+        """The kernel family a transform runs on with the plan's current setting (what PATH_AUTO resolves to for a
+        batch of ``n_units`` patches / a frame)."""
+        return self._lib.zk_plan_resolved_path(self._h, mode, dtype_code_, n_units)
 
     @property
     def disk_pixels(self):

@@ -21,7 +21,7 @@ from scipy.special import factorial
 
 __all__ = [
     "radial_polynomial", "zernike_basis", "unit_disk_area",
-    "moments_patches", "moments_frame_fft", "moments_frame_direct",
+    "moments_patches", "moments_frame_fft", "moments_frame_direct", "convolution_basis",
     "nm2j", "nm2j_complex", "complex_matrix", "real_matrix", "rot_maps_matrix",
     "sort_by_nm", "valid_mask", "to_complex", "to_real", "normalize", "select", "unselect",
     "rotate", "rot_maps", "mirror_map",
@@ -121,6 +121,19 @@ def moments_frame_direct(image: np.ndarray, basis: np.ndarray, rows=None, cols=N
         block = win[i, cols].reshape(len(cols), size * size)
         out[:, a, :] = (block @ flat_b.T).T
     return out / unit_disk_area(size)
+
+
+def convolution_basis(basis: np.ndarray, n: np.ndarray) -> np.ndarray:
+    """The numbers the reference's dense path multiplies a window with: ``(-1)^n * V[::-1, ::-1]``.
+
+    ``_zps.py:165`` CONVOLVES the image with ``V`` (the kernel is applied point-flipped) and ``:173-178`` multiplies by
+    ``(-1)^n``, which undoes the flip for an exactly point-symmetric ``V``.  The reference's float64 basis is
+    point-symmetric only up to rounding -- 1e-13 of max|V| at n_max 10, 3e-10 at 20, 1e-8 at 24 -- so at high orders
+    ``moments_frame_direct(image, V)`` (the inner-product definition) is that far from the reference's output while
+    ``moments_frame_direct(image, convolution_basis(V, n))`` restates it to 1e-16 at every order
+    (tests/test_oracle_golden.py::test_structured_goldens_pin_the_oracle)."""
+    sign = np.where(np.asarray(n) % 2 == 0, 1.0, -1.0)
+    return sign[:, None, None] * basis[:, ::-1, ::-1]
 
 
 def moments_frame_at(image: np.ndarray, basis: np.ndarray, rows, cols) -> np.ndarray:

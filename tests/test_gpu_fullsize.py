@@ -44,7 +44,7 @@ def _positions(H, K, rng, n_random=240):
 
 
 def _oracle_at(zo, frame, z, rows, cols):
-    return zo.moments_frame_at(frame, z.polynomials, rows, cols)
+    return zo.moments_frame_at(frame, zo.convolution_basis(z.polynomials, z.n), rows, cols)   # the reference's dense path
 
 
 @pytest.mark.parametrize("n_max,size,step,floor", [(12, 64, 12, 1e-11), (10, 32, 12, 1e-12)])
