@@ -778,17 +778,46 @@ def multi_rank_sections(args, comm, rank, world, dev, plan, z, dead, limit):
 # ---------------------------------------------------------------------------------------------------------
 # the other single-GPU BASELINE configs, each with its own roofline (N = 1, rank 0)
 # ---------------------------------------------------------------------------------------------------------
-def _profiled(plan, fn, reps):
+class _Timed(dict):
+    """Result of _profiled: the median pass (``ms``) with its spread, how it was taken, and the shader clock meanwhile."""
+    ms = property(lambda self: self["kernel_ms"])
+
+
+def _profiled(plan, fn, reps=10, warm_ms=40.0):
+    """Kernel time of one pass of ``fn`` (HIP events around every launch, zk_plan_profile), taken in the chip's STEADY state:
+    untimed passes run back to back until >= ``warm_ms`` of kernel time have gone by (the power management moves the shader
+    clock for the first ~15 ms of an FP64-heavy load: 2.05 GHz on the first launches, a dip to 1.7 around the 4th, 2.15-2.2
+    from ~20 ms on -- profiles/r04_strip_clock_series.txt), then ``reps`` (>= 10) timed passes back to back.
+    Returns the median pass with minimum / maximum, and the mean shader clock over the timed passes (zk_clock_monitor)."""
+    import statistics
     import torch
+    from mtflearn_amd import _native
+    reps = max(10, int(reps))
+    plan.profile(True)
     fn()
     torch.cuda.synchronize()
-    plan.profile(True)
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize()
-    launches, ms = plan.profile_read()
+    launches, first_ms = plan.profile_read()
+    warm = max(2, min(40, int(warm_ms / max(first_ms, 1e-3)) + 1))
     plan.profile(False)
-    return ms / reps, launches // reps
+    for _ in range(warm):
+        fn()
+    torch.cuda.current_stream().synchronize()          # (the monitor's window then holds the timed passes only)
+    plan.profile(True)
+    with _native.ClockMonitor(torch.cuda.current_device()) as clock:
+        for _ in range(reps):
+            fn()
+        torch.cuda.current_stream().synchronize()      # (a DEVICE synchronisation would wait for the monitor itself)
+    per_launch = plan.profile_read_launches()
+    plan.profile(False)
+    assert len(per_launch) == launches * reps, (len(per_launch), launches, reps)
+    passes = [sum(per_launch[k * launches:(k + 1) * launches]) for k in range(reps)]
+    return _Timed(kernel_ms=statistics.median(passes), kernel_ms_min=min(passes), kernel_ms_max=max(passes), timed_passes=reps,
+                  warm_passes=warm + 1, launches_per_pass=launches, shader_clock_ghz=clock.ghz)
+
+
+def _spread(t):
+    """The measurement record every side section carries beside its median."""
+    return {k: t[k] for k in ("kernel_ms_min", "kernel_ms_max", "timed_passes", "warm_passes", "shader_clock_ghz")}
 
 
 def _hbm_roofline(bytes_per_pass, ms):
@@ -797,12 +826,19 @@ def _hbm_roofline(bytes_per_pass, ms):
     return {"bound": "hbm", "achieved": a, "peak": rl.HBM_PEAK_GBS, "unit": "GB/s", "frac": a / rl.HBM_PEAK_GBS}
 
 
-def _fp64_roofline(flops_per_pass, bytes_per_pass, ms):
+def _fp64_roofline(flops_per_pass, bytes_per_pass, ms, clock_ghz=None):
+    """Fraction of the FP64 vector peak (78.6 TFLOP/s at the nominal 2.4 GHz) of the MEDIAN pass; with the shader clock
+    measured during the timed passes also against the peak at THAT clock: what the kernel makes of the cycles it is given."""
     from mtflearn_amd import roofline as rl
     t = flops_per_pass / (ms * 1e-3) / 1e12
-    return {"bound": "fp64-valu", "achieved": t, "peak": rl.FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s (executed f64)",
-            "frac": t / rl.FP64_VECTOR_PEAK_TF, "hbm_GBps_algorithmic": bytes_per_pass / (ms * 1e-3) / 1e9,
-            "hbm_frac": bytes_per_pass / (ms * 1e-3) / 1e9 / rl.HBM_PEAK_GBS}
+    r = {"bound": "fp64-valu", "achieved": t, "peak": rl.FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s (executed f64)",
+         "frac": t / rl.FP64_VECTOR_PEAK_TF, "hbm_GBps_algorithmic": bytes_per_pass / (ms * 1e-3) / 1e9,
+         "hbm_frac": bytes_per_pass / (ms * 1e-3) / 1e9 / rl.HBM_PEAK_GBS}
+    if clock_ghz:
+        r["shader_clock_ghz"] = clock_ghz
+        r["peak_at_clock"] = rl.FP64_VECTOR_PEAK_TF * clock_ghz / 2.4
+        r["frac_at_clock"] = t / r["peak_at_clock"]
+    return r
 
 
 def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
@@ -824,16 +860,17 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
             if not plan.has_path(1, _native.ZK_F32, path):
                 continue
             plan.set_path(path)
-            ms, _ = _profiled(plan, lambda: D.frame_moments_device(plan, f_dev, out=out_f), 5)
-            entry = {"patches_per_s": npx / (ms * 1e-3), "kernel_ms": ms}
+            t = _profiled(plan, lambda: D.frame_moments_device(plan, f_dev, out=out_f))
+            ms = t.ms
+            entry = {"patches_per_s": npx / (ms * 1e-3), "kernel_ms": ms, **_spread(t)}
             if path == _native.PATH_SEPARABLE:
                 entry["kernel"] = "zk_frame_strip2_kernel" if strip else "zk_frame_sep_kernel"
                 entry["fp64_flops_per_position"] = flops
-                entry["roofline"] = _fp64_roofline(npx * flops, npx * rl.dense_bytes_per_position(n_max), ms)
+                entry["roofline"] = _fp64_roofline(npx * flops, npx * rl.dense_bytes_per_position(n_max), ms, t["shader_clock_ghz"])
             else:
                 entry["kernel"] = "zk_frame_fold_kernel"
                 entry["roofline"] = _fp64_roofline(npx * (rl.direct_flops_per_unit(z.polynomials[0], n_max) / 4 + 8 * K * K / 4),
-                                                   npx * rl.dense_bytes_per_position(n_max), ms)
+                                                   npx * rl.dense_bytes_per_position(n_max), ms, t["shader_clock_ghz"])
             dense["kernels"][_native.PATH_NAMES[path]] = entry
         plan.set_path(_native.PATH_AUTO)
         result["dense_frame"] = dense
@@ -845,15 +882,17 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
         per_rank = 8
         frames = torch.stack([torch.from_numpy(honeycomb_frame(H, seed=1000 + i)) for i in range(per_rank)]).to(dev)
         full = torch.empty((per_rank, n_poly, H, H), dtype=torch.float64, device=dev)
-        ms, launches = _profiled(plan, lambda: [D.frame_moments_device(plan, frames[i], out=full[i]) for i in range(per_rank)], 3)
+        t = _profiled(plan, lambda: [D.frame_moments_device(plan, frames[i], out=full[i]) for i in range(per_rank)])
+        ms, launches = t.ms, t["launches_per_pass"]
         strip = rl.strip2_available(K, n_max) and not os.environ.get("ZK_NO_STRIP")
         flops = rl.strip2_flops_per_unit(z.polynomials[0], n_max) if strip else rl.sep_flops_per_unit(z.polynomials[0], n_max)
         result["config3_per_gpu"] = {
             "workload": f"configs[3], one GPU's share of the 64-frame batch: {per_rank} synthetic {H}x{H} frames, dense {K}-px moments "
                         f"-> ({per_rank}, {n_poly}, {H}, {H}) float64 ({full.numel() * 8 / 1e9:.1f} GB); N > 1 adds the all-gather "
                         f"('multi_frame')",
-            "kernel_ms_per_pass": ms, "launches_per_pass": launches, "positions_per_s": per_rank * H * H / (ms * 1e-3),
-            "roofline": _fp64_roofline(per_rank * H * H * flops, per_rank * H * H * rl.dense_bytes_per_position(n_max), ms)}
+            "kernel_ms_per_pass": ms, "launches_per_pass": launches, "positions_per_s": per_rank * H * H / (ms * 1e-3), **_spread(t),
+            "roofline": _fp64_roofline(per_rank * H * H * flops, per_rank * H * H * rl.dense_bytes_per_position(n_max), ms,
+                                       t["shader_clock_ghz"])}
         del frames, full
         torch.cuda.empty_cache()
 
@@ -865,11 +904,12 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
             f4 = torch.from_numpy(honeycomb_frame(4096, seed=2)).to(dev)
             p4 = f4.unfold(0, K, 1).unfold(1, K, 1).reshape(-1, K, K).contiguous()
             o4 = torch.empty((n4, n_poly), dtype=torch.float64, device=dev)
-            ms, _ = _profiled(plan, lambda: D.patch_moments_device(plan, p4, out=o4), 5)
+            t = _profiled(plan, lambda: D.patch_moments_device(plan, p4, out=o4))
+            ms = t.ms
             result["north_star_4096"] = {
                 "workload": f"north_star: all {n4} dense {K}-px windows of a 4096x4096 frame as one float32 batch "
                             f"({n4 * K * K * 4 / 1e9:.1f} GB), n_max={n_max}",
-                "kernel_ms": ms, "patches_per_s": n4 / (ms * 1e-3),
+                "kernel_ms": ms, "patches_per_s": n4 / (ms * 1e-3), **_spread(t),
                 "roofline": _hbm_roofline(n4 * rl.batch_bytes_per_patch(K, n_max), ms)}
             del p4, o4, f4
             torch.cuda.empty_cache()
@@ -882,24 +922,26 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
         rows = 496                                                       # 496 x 4033 = 2.0 M windows = 32.8 GB
         p2 = f2[:rows + 63].unfold(0, 64, 1).unfold(1, 64, 1).reshape(-1, 64, 64).contiguous()
         o2 = torch.empty((p2.shape[0], 91), dtype=torch.float64, device=dev)
-        ms, _ = _profiled(plan12, lambda: D.patch_moments_device(plan12, p2, out=o2), 5)
+        t = _profiled(plan12, lambda: D.patch_moments_device(plan12, p2, out=o2))
+        ms = t.ms
         result["config2_batch"] = {
             "workload": f"configs[2] in batch form: {p2.shape[0]} dense 64-px windows (the first {rows} window rows of a "
                         f"4096x4096 frame; all 16.3 M would be 266 GB) as one float32 batch, n_max=12 (91 moments)",
-            "kernel_ms": ms, "patches_per_s": p2.shape[0] / (ms * 1e-3),
+            "kernel_ms": ms, "patches_per_s": p2.shape[0] / (ms * 1e-3), **_spread(t),
             "roofline": _hbm_roofline(p2.shape[0] * rl.batch_bytes_per_patch(64, 12), ms)}
         del p2, o2
         torch.cuda.empty_cache()
         od = torch.empty((91, 4096, 4096), dtype=torch.float64, device=dev)
-        ms, _ = _profiled(plan12, lambda: D.frame_moments_device(plan12, f2, out=od), 3)
+        t = _profiled(plan12, lambda: D.frame_moments_device(plan12, f2, out=od))
+        ms = t.ms
         strip12 = rl.strip2_available(64, 12) and not os.environ.get("ZK_NO_STRIP") and not os.environ.get("ZK_STRIP_NO_SPLIT")
         flops = rl.strip2_flops_per_unit(z12.polynomials[0], 12) if strip12 else rl.sep_flops_per_unit(z12.polynomials[0], 12)
         result["config2_dense"] = {
             "workload": "configs[2]: 4096x4096 frame, every 64-px window (zero-padded 'same' positions), n_max=12 -> (91, 4096, 4096) float64",
             "kernel": "zk_frame_strip2_kernel<12> (two outputs per lane, two passes by x parity)" if strip12 else "zk_frame_sep_kernel<12>",
-            "kernel_ms": ms, "positions_per_s": 4096 * 4096 / (ms * 1e-3),
+            "kernel_ms": ms, "positions_per_s": 4096 * 4096 / (ms * 1e-3), **_spread(t),
             "fp64_flops_per_position": flops,
-            "roofline": _fp64_roofline(4096 * 4096 * flops, 4096 * 4096 * rl.dense_bytes_per_position(12), ms)}
+            "roofline": _fp64_roofline(4096 * 4096 * flops, 4096 * 4096 * rl.dense_bytes_per_position(12), ms, t["shader_clock_ghz"])}
         del od, f2, plan12, z12
         torch.cuda.empty_cache()
 
@@ -914,19 +956,22 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
             rot = torch.empty((4, 4096, 4096), dtype=torch.float64, device=dev)
             ab = torch.empty((n_c, 4096, 4096), dtype=torch.float64, device=dev)
             mir = torch.empty((4096, 4096), dtype=torch.float64, device=dev)
-            ms, _ = _profiled(plan10, lambda: D.frame_maps_device(plan10, big, n_c, theta=theta, full=(rot, ab, mir)), 3)
+            t = _profiled(plan10, lambda: D.frame_maps_device(plan10, big, n_c, theta=theta, full=(rot, ab, mir)))
+            ms = t.ms
             del rot, ab, mir
             mom = torch.empty((66, 4096, 4096), dtype=torch.float64, device=dev)
-            ms2, _ = _profiled(plan10, lambda: D.frame_moments_device(plan10, big, out=mom), 3)
+            t2 = _profiled(plan10, lambda: D.frame_moments_device(plan10, big, out=mom))
+            ms2 = t2.ms
             del mom
             flops = rl.sep_flops_per_unit(z10.polynomials[0], 10) + rl.maps_tail_flops(10, 4, 360)
             result["symmetry_pipeline"] = {
                 "workload": "configs[4]: 4096x4096 frame, 32-px, n_max=10 -> rot_maps[2,3,4,6] + 36 |Z_nm| planes + "
                             "mirror_map(360 angles), fused in one kernel",
-                "kernel": "zk_frame_maps_kernel<10>", "fused_kernel_ms": ms, "positions_per_s": 4096 * 4096 / (ms * 1e-3),
-                "moments_only_kernel_ms": ms2, "fp64_flops_per_position": flops,
+                "kernel": "zk_frame_maps_kernel<10>", "fused_kernel_ms": ms, "positions_per_s": 4096 * 4096 / (ms * 1e-3), **_spread(t),
+                "moments_only_kernel_ms": ms2, "moments_only": _spread(t2), "fp64_flops_per_position": flops,
                 "out_bytes_fused": 41 * 4096 * 4096 * 8, "out_bytes_moments": 66 * 4096 * 4096 * 8,
-                "roofline": _fp64_roofline(4096 * 4096 * flops, 4096 * 4096 * rl.dense_bytes_per_position(10, planes=41), ms)}
+                "roofline": _fp64_roofline(4096 * 4096 * flops, 4096 * 4096 * rl.dense_bytes_per_position(10, planes=41), ms,
+                                           t["shader_clock_ghz"])}
         del big
         torch.cuda.empty_cache()
 

@@ -234,8 +234,9 @@ int zk_frame_maps_dev_strided(zk_plan* plan, const void* image_dev, int dtype, i
  */
 int zk_plan_profile(zk_plan* plan, int enable);
 int zk_plan_profile_read(zk_plan* plan, int64_t* launches, double* total_ms);
-/* Same, launch by launch: the first `cap` kernel times (ms, in launch order) since the last read go to ms_out and
- * their number to *n_out (bench.py: minimum / median / maximum of the timed steps). */
+/* Same, launch by launch: the first `cap` kernel times (ms, in launch order) since the last read go to ms_out; *n_out =
+ * the number of launches RECORDED since the last read -- larger than `cap` when the list handed back is incomplete (the
+ * rest is dropped; bench.py: minimum / median / maximum of the timed steps). */
 int zk_plan_profile_read_launches(zk_plan* plan, double* ms_out, int64_t cap, int64_t* n_out);
 
 /*
@@ -483,6 +484,15 @@ int zk_device_synchronize(int device);
  *                                            (23040 = 64 patches x 45 moments per 256 KiB of float32 32-px patches).
  * *ms_out = average over `reps` launches after one warm-up. */
 int zk_hbm_probe(int device, const void* src_dev, void* dst_dev, int64_t bytes, int64_t store_per_group, int reps, double* ms_out);
+
+/* The shader clock while other work runs on the device (measurement aid of bench.py; no reference counterpart): start puts ONE
+ * wave on a stream of its own that samples the shader-clock counter against the constant 100-MHz counter and then naps until
+ * stop is called or `max_ms` (<= 2000) have passed; stop returns the mean clock in GHz over the `ms` the wave was resident.
+ * The FP64-bound kernels of this library run at 1.7-2.2 GHz of the nominal 2.4 (power management), so their rates are stated
+ * against the measured clock as well as the nominal one. */
+typedef struct zk_clock_monitor zk_clock_monitor;
+int zk_clock_monitor_start(int device, double max_ms, zk_clock_monitor** out);
+int zk_clock_monitor_stop(zk_clock_monitor* monitor, double* ghz_out, double* ms_out);
 
 #ifdef __cplusplus
 }

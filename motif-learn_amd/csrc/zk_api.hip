@@ -67,9 +67,10 @@ extern "C" int zk_plan_profile(zk_plan* p, int enable) {
   return 0;
 }
 
-// resolves the recorded event pairs; the first `cap` per-launch times go to ms_out (may be NULL)
-static int prof_drain(zk_plan* p, double* ms_out, int64_t cap, int64_t* n_written) {
-  int64_t w = 0;
+// resolves the recorded event pairs; the first `cap` per-launch times go to ms_out (may be NULL); *n_recorded = how many
+// launches were recorded (may exceed cap: the caller sees that its list is incomplete)
+static int prof_drain(zk_plan* p, double* ms_out, int64_t cap, int64_t* n_recorded) {
+  int64_t w = 0, total = 0;
   for (size_t k = 0; k + 1 < p->ev_used; k += 2) {
     ZK_HIP(hipEventSynchronize(p->ev_pool[k + 1]));
     float ms = 0.f;
@@ -77,9 +78,10 @@ static int prof_drain(zk_plan* p, double* ms_out, int64_t cap, int64_t* n_writte
     p->prof_ms += ms;
     p->prof_launches += 1;
     if (ms_out && w < cap) ms_out[w++] = (double)ms;
+    ++total;
   }
   p->ev_used = 0;
-  if (n_written) *n_written = w;
+  if (n_recorded) *n_recorded = total;
   return 0;
 }
 

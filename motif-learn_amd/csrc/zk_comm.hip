@@ -21,6 +21,8 @@
 
 #include <rccl/rccl.h>  // types and prototypes only; nothing here links against librccl
 
+#include <new>
+
 #include "zk_internal.h"
 
 static_assert(ZK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
@@ -286,8 +288,20 @@ extern "C" int zk_comm_init_tcp(int device, int rank, int world, const char* hos
       sockaddr_in a = {};
       a.sin_family = AF_INET;
       a.sin_port = htons((uint16_t)port);
-      // listen on the address the peers were told to use, not on every interface
-      if (inet_pton(AF_INET, host, &a.sin_addr) != 1) {
+      // Listen on the address the peers were told to use rather than on every interface -- but only where that is known
+      // to be an address of THIS machine the peers can reach: a literal IP keeps the narrow bind; a NAME that resolves to
+      // loopback (the 127.0.1.1 many distributions map the local hostname to) would leave remote ranks timing out, and an
+      // address that is not assigned locally (a VIP, a NAT or service address) cannot be bound at all -- both fall back
+      // to every interface.  ZK_COMM_BIND_ADDR (an IPv4 literal, or "any") overrides.
+      bool literal = inet_pton(AF_INET, host, &a.sin_addr) == 1;
+      const char* force = getenv("ZK_COMM_BIND_ADDR");
+      if (force && *force) {
+        if (!strcmp(force, "any")) a.sin_addr.s_addr = htonl(INADDR_ANY);
+        else if (inet_pton(AF_INET, force, &a.sin_addr) != 1) {
+          close(ls);
+          return zk_fail(ZK_E_COMM, std::string("ZK_COMM_BIND_ADDR is neither an IPv4 literal nor \"any\": ") + force);
+        }
+      } else if (!literal) {
         addrinfo hints = {}, *res = nullptr;
         hints.ai_family = AF_INET;
         hints.ai_socktype = SOCK_STREAM;
@@ -297,8 +311,15 @@ extern "C" int zk_comm_init_tcp(int device, int rank, int world, const char* hos
         }
         a.sin_addr = ((sockaddr_in*)res->ai_addr)->sin_addr;
         freeaddrinfo(res);
+        const bool loopback = (ntohl(a.sin_addr.s_addr) >> 24) == 127;
+        if (loopback && strcmp(host, "localhost") != 0) a.sin_addr.s_addr = htonl(INADDR_ANY);
       }
-      if (bind(ls, (sockaddr*)&a, sizeof a) != 0 || listen(ls, world) != 0) {
+      int brc = bind(ls, (sockaddr*)&a, sizeof a);
+      if (brc != 0 && errno == EADDRNOTAVAIL && !(force && *force)) {  // not an address of this machine: every interface
+        a.sin_addr.s_addr = htonl(INADDR_ANY);
+        brc = bind(ls, (sockaddr*)&a, sizeof a);
+      }
+      if (brc != 0 || listen(ls, world) != 0) {
         const std::string why = strerror(errno);
         close(ls);
         return zk_fail(ZK_E_COMM, "cannot listen on port " + std::to_string(port) + ": " + why);
@@ -619,6 +640,96 @@ extern "C" int zk_hbm_probe(int device, const void* src, void* dst, int64_t byte
   (void)hipFree(sink);
   if (e != hipSuccess) return zk_hip_fail(e, "zk_hbm_probe");
   *ms_out = (double)ms / reps;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Shader clock while other kernels run (bench.py: every FP64-bound section is reported against the clock it actually ran
+// at -- the chip's power management holds this class of kernel at 1.7-2.2 GHz of the nominal 2.4, profiles/r04_strip_trace.txt).
+// One wave on a stream of its own: it reads the shader-clock counter (s_memtime) against the constant 100-MHz counter
+// (s_memrealtime), then sleeps in short naps until the host clears its run flag (page-locked, mapped) or its budget of
+// 100-MHz ticks is spent -- an exit every wave reaches whatever the host does -- and reads both again.
+// ------------------------------------------------------------------------------------------------------------------------
+struct zk_clock_monitor {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  volatile int* h_flag = nullptr;        // host-mapped: 1 = keep running
+  unsigned long long* h_out = nullptr;   // host-mapped: rt0, ck0, rt1, ck1
+};
+
+namespace {
+__global__ void clock_monitor_kernel(volatile int* flag, unsigned long long* out, unsigned long long budget_ticks, int mode) {
+  if (threadIdx.x != 0 && mode != 2) return;
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    out[0] = rt0;
+    out[1] = ck0;
+  }
+  unsigned long long rt = rt0;
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0;
+  for (int spin = 0; spin < (1 << 24); ++spin) {             // (hard cap on iterations besides the tick budget)
+    if (mode == 0) __builtin_amdgcn_s_sleep(100);            // ~6400 clocks: the wave costs its SIMD next to nothing
+    if (mode == 2) {
+#pragma unroll
+      for (int k = 0; k < 64; ++k) b = __builtin_fma(b, a, 1e-300);
+    }
+    rt = __builtin_amdgcn_s_memrealtime();
+    if (rt - rt0 >= budget_ticks || __hip_atomic_load((const int*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) break;
+  }
+  if (threadIdx.x == 0) {
+    out[2] = __builtin_amdgcn_s_memrealtime();
+    out[3] = __builtin_amdgcn_s_memtime();
+    out[4] = (unsigned long long)b;
+  }
+}
+}  // namespace
+
+extern "C" int zk_clock_monitor_start(int device, double max_ms, zk_clock_monitor** out) {
+  if (!out || !(max_ms > 0.0) || max_ms > 2000.0) return zk_fail(ZK_E_BADARG, "need out and 0 < max_ms <= 2000");
+  *out = nullptr;
+  ZK_ON_DEVICE(device);
+  zk_clock_monitor* m = new (std::nothrow) zk_clock_monitor();
+  if (!m) return zk_fail(ZK_E_NOMEM, "out of host memory");
+  m->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&m->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&m->h_out, 64, hipHostMallocMapped | hipHostMallocCoherent);
+  int* d_flag = nullptr;
+  unsigned long long* d_out = nullptr;
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&d_flag, (void*)m->h_flag, 0);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&d_out, (void*)m->h_out, 0);
+  if (e == hipSuccess) {
+    *m->h_flag = 1;
+    for (int k = 0; k < 4; ++k) m->h_out[k] = 0;
+    const char* md = getenv("ZK_CLOCK_MONITOR_MODE");
+    hipLaunchKernelGGL(clock_monitor_kernel, dim3(1), dim3(64), 0, m->stream, (volatile int*)d_flag, d_out,
+                       (unsigned long long)(max_ms * 1e5), md ? atoi(md) : 0);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) {
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->h_flag) (void)hipHostFree((void*)m->h_flag);
+    if (m->h_out) (void)hipHostFree(m->h_out);
+    delete m;
+    return zk_hip_fail(e, "zk_clock_monitor_start");
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" int zk_clock_monitor_stop(zk_clock_monitor* m, double* ghz_out, double* ms_out) {
+  if (!m) return zk_fail(ZK_E_BADARG, "null monitor");
+  ZK_ON_DEVICE(m->device);
+  __atomic_store_n((int*)m->h_flag, 0, __ATOMIC_SEQ_CST);
+  hipError_t e = hipStreamSynchronize(m->stream);
+  const double ticks = (double)(m->h_out[2] - m->h_out[0]), clocks = (double)(m->h_out[3] - m->h_out[1]);
+  if (ghz_out) *ghz_out = ticks > 0 ? clocks / (ticks * 10.0) : 0.0;
+  if (ms_out) *ms_out = ticks / 1e5;
+  (void)hipStreamDestroy(m->stream);
+  (void)hipHostFree((void*)m->h_flag);
+  (void)hipHostFree(m->h_out);
+  delete m;
+  if (e != hipSuccess) return zk_hip_fail(e, "zk_clock_monitor_stop");
   return 0;
 }
 

@@ -182,6 +182,18 @@ typedef double zk_v4d __attribute__((ext_vector_type(4)));
 typedef double zk_v2d __attribute__((ext_vector_type(2)));
 template <int N>
 struct zk_sgpr_row;  // N doubles of one table row in SGPRs
+#ifdef ZK_EXP_HALF_TABLE  // timing experiment only (wrong moments): half the scalar bytes per column pair, every value used twice
+template <>
+struct zk_sgpr_row<8> {
+  zk_v4d v;
+  template <int OFF>
+  __device__ __forceinline__ void request(const ZK_CONST double* p, double& after) {
+    asm volatile("s_load_dwordx8 %0, %2, %3" : "=s"(v), "+v"(after) : "s"(p), "n"(OFF));
+  }
+  __device__ __forceinline__ void wait(double& a, double& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+v"(a), "+v"(b)); }
+  __device__ __forceinline__ double operator[](int i) const { return v[i & 3]; }
+};
+#else
 template <>
 struct zk_sgpr_row<8> {
   zk_v8d v;
@@ -192,6 +204,7 @@ struct zk_sgpr_row<8> {
   __device__ __forceinline__ void wait(double& a, double& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+v"(a), "+v"(b)); }
   __device__ __forceinline__ double operator[](int i) const { return v[i]; }
 };
+#endif
 template <>
 struct zk_sgpr_row<6> {
   zk_v4d a;
@@ -360,6 +373,37 @@ __device__ __forceinline__ void zk_strip_pass(const double* __restrict__ tile, c
   });
 }
 
+// Tools-only build (-DZK_STRIP_TRACE, tools/strip_trace.py): every workgroup leaves its timeline -- the 100-MHz
+// constant clock and the shader clock at its start, after staging, after the arithmetic + store issue, after its stores
+// have drained, and where it ran (HW_ID, XCC_ID) -- in a buffer the tool hands in.  Not part of the product library.
+#ifdef ZK_STRIP_TRACE
+__device__ unsigned long long* zk_strip_trace_buf = nullptr;
+extern "C" int zk_debug_strip_trace(unsigned long long* dev_buf) {
+  ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(zk_strip_trace_buf), &dev_buf, sizeof(dev_buf)));
+  return 0;
+}
+#define ZK_TRACE_STAMP(slot)                                                  \
+  unsigned long long zk_rt_##slot = __builtin_amdgcn_s_memrealtime(), zk_ck_##slot = __builtin_amdgcn_s_memtime();
+#define ZK_TRACE_RECORD()                                                                                        \
+  {                                                                                                              \
+    ZK_TRACE_STAMP(2)                                                                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
+    ZK_TRACE_STAMP(3)                                                                                            \
+    if (zk_strip_trace_buf && (threadIdx.x & 63) == 0) {                                                         \
+      unsigned hw, xcc;                                                                                          \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                           \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                         \
+      unsigned long long* r = zk_strip_trace_buf + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 10; \
+      r[0] = zk_rt_0; r[1] = zk_rt_1; r[2] = zk_rt_2; r[3] = zk_rt_3;                                            \
+      r[4] = zk_ck_0; r[5] = zk_ck_1; r[6] = zk_ck_2; r[7] = zk_ck_3;                                            \
+      r[8] = hw; r[9] = xcc;                                                                                     \
+    }                                                                                                            \
+  }
+#else
+#define ZK_TRACE_STAMP(slot)
+#define ZK_TRACE_RECORD()
+#endif
+
 template <int NMAX, typename T, int QM>
 __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
     const T* __restrict__ img, double* __restrict__ out, const int32_t* __restrict__ row_tab,
@@ -373,8 +417,10 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
   const int i0 = row0 + blockIdx.y * 8;
   const int k0 = blockIdx.x * 64;
 
+  ZK_TRACE_STAMP(0)
   zk_stage_tile(tile, img, H, W, i0 - ea, k0 - ea, K + 7, tile_pitch);
   __syncthreads();
+  ZK_TRACE_STAMP(1)
 
   const int ok = k0 + lane;
   const int oi = i0 + 2 * wave;
@@ -390,6 +436,167 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
     zk_strip_pass<NMAX, QM, (1 << ZK_OE) | (1 << ZK_OO)>(tile, zk_const(row_tab), zk_const(xtab), zk_const(pfull), zk_const(tmat),
                                                          zk_const(colmap), dst, store, two, K, W, tile_pitch, plane, wave, lane);
   }
+  ZK_TRACE_RECORD()
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the x table in VGPR LANES (even K <= 32, n_max <= 8: configs[1] dense and configs[3]).
+// profiles/r04_strip_trace.txt: the wave slots of zk_frame_strip2_kernel<8> are occupied 0.96-0.98 of the kernel's
+// duration -- no dispatch gap -- and its 0.73 VALU-busy is the scalar data path: a sweep block needs 8 fresh SGPR doubles
+// (64 B) per 11 f64 operations, eight waves of a CU ask for 5.8 B per clock where the scalar cache delivers ~5.6,
+// i.e. the 0.7 FMA per clock a CU gets from once-used scalars.  Fetching half the table row (ZK_EXP_HALF_TABLE, wrong
+// results, timing only) took the wave's life from 96.1 k to 85.0 k clocks.  So the sweeps here take NO scalar operand:
+//   * the whole x table of the window -- P_1 .. P_nmax of the 16 column pairs, 128 doubles -- lives in 8 VGPR pairs, lane
+//     e of every row of 16 lanes holding entry e (two columns x 8 degrees per register pair), loaded once per workgroup;
+//     a block multiplies with `v_fmac_f64_dpp ... row_newbcast:e` (the one DPP control the FP64 pipe accepts: lane e of
+//     the lane's own row of 16, measured at the plain instruction's rate, tools/micro_dpp64.hip);
+//   * with no scalar-memory request in a sweep its LDS requests complete in order, so the pixel pairs run TWO blocks ahead
+//     and a block waits with lgkmcnt(2) for its own pair only (scalar loads return out of order: with them in flight only
+//     lgkmcnt(0) is safe, which is why the round-3 pipeline was one block deep);
+//   * a register-resident table cannot be entered at a run-time column, so a frame row is ONE sweep over the columns of
+//     the wider output: the sums are copied when they pass the narrower output's limit (block n1) and both row steps
+//     follow the sweep -- one start-up and one drain per frame row instead of two of each.
+// MEASURED (profiles/r04_strip3.txt, same box, steady state): scalar-memory instructions -63 %, the wave's life 97.3 k ->
+// 102.6 k clocks, the shader clock 2.19 -> 2.28 GHz (less power), the kernel 0.738 -> 0.745 ms per 2048^2: a draw.  The DPP
+// form reads three 64-bit VGPR operands where the scalar form reads two (the VGPR-operand v_fmac_f64 runs at 0.8 of the
+// SGPR-operand one, tools/micro_dpp64.hip), the sweep carries a second branch per block, and VALU-busy stays at 0.73.
+// Requesting the y rows and the next record by hand at the row's start (they would ride on the sweep) needs 33 more live
+// SGPRs: 584 bytes of scratch.  Kept as an opt-in (ZK_STRIP_V3=1 in the environment, parity-tested) and as the record of
+// what bounds the round-3 kernel; ZK_PATH_AUTO stays on zk_frame_strip2_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef ZK_STRIP3
+#define ZK_STRIP3 1
+#endif
+
+template <int E>  // acc += T[lane E of my row of 16] * x
+__device__ __forceinline__ void zk_fmac_bcast(double& acc, double t, double x) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(x), "n"(E));
+}
+template <int N>  // all but the newest N of this wave's LDS requests have landed; a and b are what the caller goes on to use
+__device__ __forceinline__ void zk_lds_wait(double& a, double& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+template <int NMAX>
+__device__ __forceinline__ void zk_strip3_pass(const double* __restrict__ tile, const ZK_CONST int32_t* rtab, const double* __restrict__ xt,
+                                               const ZK_CONST double* py, const ZK_CONST double* tb, const ZK_CONST int32_t* cmap,
+                                               double* __restrict__ dst, bool store, bool two, int K, int W, int tile_pitch,
+                                               long long plane, int wave, int lane) {
+  using S = zk_sep_set<NMAX>;
+  constexpr int YROW = ZK_STREAM_ROW(NMAX), XROW = YROW, QM = 16;
+  const int Q = K / 2;
+  zk_sep_acc<NMAX> acc0, acc1;  // moments of output rows i0 + 2 wave and i0 + 2 wave + 1 (only M is used)
+  acc0.clear_moments();
+  acc1.clear_moments();
+  // register pair c, lane e of a row of 16: P_{(e & 7) + 1} of column pair 2 c + (e >> 3) (sweep index: 0 = the centre columns)
+  double T[8];
+  {
+    const int e = lane & 15, deg = e & 7;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int col = Q + 2 * c + (e >> 3);
+      T[c] = (deg < NMAX && col < K) ? xt[col * XROW + deg] : 0.0;
+    }
+  }
+  const double* __restrict__ mine = tile + (2 * wave) * tile_pitch + lane;  // window row 0 of output 0
+
+  auto frame_row = [&](int fr, auto first_is_1) __attribute__((always_inline)) {
+    constexpr bool F1 = decltype(first_is_1)::value;
+    const int rec = rtab[fr];
+    if (rec == 0) return;  // no disk pixel of either output in this frame row
+    const int n1 = rec & 0xff, ntot = n1 + (rec >> 8);
+    double X[S::NA], Xs[S::NA];
+#pragma unroll
+    for (int i = 0; i < S::NA; ++i) X[i] = Xs[i] = 0.0;
+    const double* __restrict__ row = mine + fr * tile_pitch;
+    // block t uses the pixels at LDS bytes La + 8 (QM-1-t) (left of the centre) and Ra + 8 t (right): immediates
+    const unsigned La = zk_lds_addr(row + (Q - 1) - (QM - 1));
+    const unsigned Ra = zk_lds_addr(row + Q);
+    double A[3], B[3];
+    A[2] = B[2] = 0.0;
+    double dep = 0.0;
+    A[0] = zk_lds_request<(QM - 1) * 8>(La, dep);
+    B[0] = zk_lds_request<0>(Ra, dep);
+    A[1] = zk_lds_request<(QM - 2) * 8>(La, dep);
+    B[1] = zk_lds_request<8>(Ra, dep);
+#define ZK_STRIP3_BLOCK(I)                                                                                   \
+  {                                                                                                          \
+    zk_lds_wait<((I) + 1 < QM ? 2 : 0)>(A[(I) % 3], B[(I) % 3]);                                             \
+    if constexpr ((I) + 2 < QM) {                                                                            \
+      A[((I) + 2) % 3] = zk_lds_request<(QM - 3 - (I) >= 0 ? QM - 3 - (I) : 0) * 8>(La, A[(I) % 3]);         \
+      B[((I) + 2) % 3] = zk_lds_request<((I) + 2) * 8>(Ra, B[(I) % 3]);                                      \
+    }                                                                                                        \
+    const double s_ = B[(I) % 3] + A[(I) % 3], d_ = B[(I) % 3] - A[(I) % 3];                                 \
+    X[0] += s_;                                                                                              \
+    zk_for_each_slot<NMAX>([&](auto k) {                                                                     \
+      constexpr int a = decltype(k)::value + 1; /* degree */                                                 \
+      zk_fmac_bcast<8 * ((I) & 1) + a - 1>(X[a], T[(I) / 2], (a & 1) ? d_ : s_);                             \
+    });                                                                                                      \
+    if (n1 == (I) + 1) { /* (the empty volatile asm keeps this a branch: if-converted it is 18 selects in EVERY block) */ \
+      asm volatile("");                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < S::NA; ++i) Xs[i] = X[i];                                        \
+    }                                                                                                        \
+  }
+#define ZK_STRIP3_STEP(I) \
+  ZK_STRIP3_BLOCK(I)      \
+  if (ntot <= (I) + 1) break;
+    do {
+      ZK_STRIP3_STEP(0) ZK_STRIP3_STEP(1) ZK_STRIP3_STEP(2) ZK_STRIP3_STEP(3) ZK_STRIP3_STEP(4) ZK_STRIP3_STEP(5)
+      ZK_STRIP3_STEP(6) ZK_STRIP3_STEP(7) ZK_STRIP3_STEP(8) ZK_STRIP3_STEP(9) ZK_STRIP3_STEP(10) ZK_STRIP3_STEP(11)
+      ZK_STRIP3_STEP(12) ZK_STRIP3_STEP(13) ZK_STRIP3_STEP(14)
+      ZK_STRIP3_BLOCK(15)
+    } while (0);
+#undef ZK_STRIP3_STEP
+#undef ZK_STRIP3_BLOCK
+    // the requests past the sweep's end have landed before anything else may live in their registers
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(B[0]), "+v"(A[1]), "+v"(B[1]), "+v"(A[2]), "+v"(B[2]));
+    // (n1 = 0 -- the first output has no disk pixel in this frame row -- leaves Xs zero: its moments do not change)
+    if constexpr (F1) {
+      acc1.stream_accumulate(Xs, py + (n1 ? fr - 1 : fr) * YROW);
+      acc0.stream_accumulate(X, py + fr * YROW);
+    } else {
+      acc0.stream_accumulate(Xs, py + fr * YROW);
+      acc1.stream_accumulate(X, py + (fr - 1) * YROW);
+    }
+  };
+  for (int fr = 0; fr < Q; ++fr) frame_row(fr, std::true_type{});
+  for (int fr = Q; fr <= K; ++fr) frame_row(fr, std::false_type{});
+
+  if (!store) return;
+  zk_sep_transform2<NMAX, 15>(acc0, acc1, tb, [&](auto slot, double z0, double z1) {
+    const int col = cmap[slot];
+    if (col >= 0) {
+      double* __restrict__ d = dst + col * plane;
+      d[0] = z0;
+      if (two) d[W] = z1;
+    }
+  });
+}
+
+template <int NMAX, typename T>
+__global__ __launch_bounds__(256, 2) void zk_frame_strip3_kernel(
+    const T* __restrict__ img, double* __restrict__ out, const int32_t* __restrict__ row_tab, const double* __restrict__ xtab,
+    const double* __restrict__ pfull, const double* __restrict__ tmat, const int32_t* __restrict__ colmap, int K, int H, int W,
+    int row0, int n_rows, int tile_pitch, long long plane) {
+  extern __shared__ __attribute__((aligned(16))) double tile[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ea = K - 1 - (K - 1) / 2;
+  const int i0 = row0 + blockIdx.y * 8;
+  const int k0 = blockIdx.x * 64;
+  ZK_TRACE_STAMP(0)
+  zk_stage_tile(tile, img, H, W, i0 - ea, k0 - ea, K + 7, tile_pitch);
+  __syncthreads();
+  ZK_TRACE_STAMP(1)
+  const int ok = k0 + lane;
+  const int oi = i0 + 2 * wave;
+  const bool store = ok < W && oi < row0 + n_rows;
+  const bool two = oi + 1 < row0 + n_rows;  // wave-uniform
+  double* __restrict__ dst = out + (long long)(oi - row0) * W + ok;
+  zk_strip3_pass<NMAX>(tile, zk_const(row_tab), xtab, zk_const(pfull), zk_const(tmat), zk_const(colmap), dst, store, two, K, W,
+                       tile_pitch, plane, wave, lane);
+  ZK_TRACE_RECORD()
 }
 
 // Also tried in round 3: requesting a sweep's FIRST operands ahead of the row step that precedes it (each of the 66 sweeps of an
@@ -427,10 +634,34 @@ int launch_strip2(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0
 }
 
 template <int NMAX, typename T>
+int launch_strip3(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out, hipStream_t s) {
+  const zk_sep_tables* t = p->sep;
+  const size_t lds = (size_t)(p->size + 7) * t->tile_pitch * sizeof(double);
+  auto kern = zk_frame_strip3_kernel<NMAX, T>;
+  if (lds > 64 * 1024)
+    ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long long plane = zk_out_plane(p, n_rows, W);
+  return zk_for_row_bands(row0, n_rows, W, 8, [&](int64_t r0, int64_t nr, long long off) {
+    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((nr + 7) / 8));
+    int rc = zk_prof_begin(p, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)in, out + off, t->d_strip_rows, t->d_pfull, t->d_pfull, t->d_T,
+                       t->d_colmap, p->size, (int)H, (int)W, (int)r0, (int)nr, t->tile_pitch, plane);
+    ZK_HIP(hipGetLastError());
+    return zk_prof_end(p, s);
+  });
+}
+
+template <int NMAX, typename T>
 int launch_one(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out,
                hipStream_t s) {
   const zk_sep_tables* t = p->sep;
   static const bool v1 = getenv("ZK_STRIP_V1") != nullptr;  // A/B runs: the round-2 kernel
+  const bool v3 = getenv("ZK_STRIP_V3") != nullptr;  // opt-in: round 4's kernel with the x table in VGPR lanes (see above)
+  if constexpr (NMAX <= 8) {
+    if (ZK_STRIP3 && !v1 && v3 && t->d_strip_rows && p->size % 2 == 0 && p->size <= 32)
+      return launch_strip3<NMAX, T>(p, in, H, W, row0, n_rows, out, s);
+  }
   if (ZK_STRIP2 && !v1 && t->d_strip_rows && p->size % 2 == 0) {
     if (p->size <= 32) return launch_strip2<NMAX, T, 16>(p, in, H, W, row0, n_rows, out, s);
     return launch_strip2<NMAX, T, 32>(p, in, H, W, row0, n_rows, out, s);

@@ -138,6 +138,8 @@ SYMBOLS = {
     "zk_device_copy": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int]),
     "zk_device_synchronize": (c_int, [c_int]),
     "zk_hbm_probe": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_double)]),
+    "zk_clock_monitor_start": (c_int, [c_int, c_double, POINTER(c_void_p)]),
+    "zk_clock_monitor_stop": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "zk_plan_profile": (c_int, [c_void_p, c_int]),
     "zk_plan_profile_read": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
     "zk_plan_profile_read_launches": (c_int, [c_void_p, POINTER(c_double), c_int64, POINTER(c_int64)]),
@@ -200,6 +202,25 @@ def device_count():
     if n < 0:
         raise RuntimeError(f"zk_device_count failed with code {n}: {last_error()}")
     return n
+
+
+class ClockMonitor:
+    """``with ClockMonitor(device) as m: ...`` -- the mean shader clock (``m.ghz``) over the ``m.ms`` the block took, sampled by
+    one resident wave (``zk_clock_monitor_start / _stop``).  Inside the block synchronise the STREAM the work runs on, not
+    the device: a device-wide synchronisation waits for the monitor's own wave, i.e. for its whole time budget."""
+
+    def __init__(self, device=0, max_ms=1500.0):
+        self.device, self.max_ms, self.ghz, self.ms, self._h = device, max_ms, None, None, c_void_p()
+
+    def __enter__(self):
+        check(load().zk_clock_monitor_start(int(self.device), float(self.max_ms), byref(self._h)), "zk_clock_monitor_start")
+        return self
+
+    def __exit__(self, *exc):
+        ghz, ms = c_double(), c_double()
+        check(load().zk_clock_monitor_stop(self._h, byref(ghz), byref(ms)), "zk_clock_monitor_stop")
+        self.ghz, self.ms = ghz.value, ms.value
+        return False
 
 
 def hbm_probe(device, src_ptr, nbytes, dst_ptr=None, store_per_group=0, reps=5):
@@ -336,11 +357,14 @@ class Plan:
         check(self._lib.zk_plan_profile_read(self._h, byref(launches), byref(ms)), "zk_plan_profile_read")
         return launches.value, ms.value
 
-    def profile_read_launches(self, cap=4096):
-        """Per-launch kernel times (ms) recorded since the last read, in launch order."""
+    def profile_read_launches(self, cap=65536):
+        """Per-launch kernel times (ms) recorded since the last read, in launch order; raises if more than ``cap``
+        launches were recorded (the library drops what does not fit -- a truncated list would skew every statistic)."""
         buf = (c_double * cap)()
         n = c_int64()
         check(self._lib.zk_plan_profile_read_launches(self._h, buf, cap, byref(n)), "zk_plan_profile_read_launches")
+        if n.value > cap:
+            raise RuntimeError(f"profile_read_launches: {n.value} launches recorded, room for {cap}")
         return list(buf[:n.value])
 
     # -- host-buffer entry points --------------------------------------------------------

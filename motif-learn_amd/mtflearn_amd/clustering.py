@@ -22,6 +22,8 @@ from __future__ import annotations
 import warnings
 from ctypes import POINTER, byref, c_double, c_int32, c_int64, c_void_p
 
+import os
+
 import numpy as np
 
 from . import _native
@@ -158,7 +160,8 @@ class DeviceRows:
         d1 = self.n_features + 1
         n = 1 if count is None else int(count)
         out = np.empty((n, d1, d1))
-        per_pass = 8 if self.n_features <= 47 else 3
+        # the matrix-core pass takes 2 .. 47 features (and ZK_WGRAM_VALU forces the vector kernel for A/B runs): otherwise three
+        per_pass = 8 if 2 <= self.n_features <= 47 and not os.environ.get("ZK_WGRAM_VALU") else 3
         for c0 in range(0, n, per_pass):
             cc = min(per_pass, n - c0)
             _native.check(self._lib.zk_gmm_moments(self._h, int(component) + c0, cc, _p(shift), _p(out[c0:c0 + cc])), "zk_gmm_moments")

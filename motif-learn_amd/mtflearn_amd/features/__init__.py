@@ -3,10 +3,10 @@ the moment container and index algebra, and the two routines that pick its param
 from .zernike_polys import ZPs
 from .moments import (zmoments, construct_rot_maps_matrix, construct_complex_matrix,
                       construct_real_matrix, nm2j, nm2j_complex, check_array1d)
-from .pickers import (estimate_patch_size, radial_profile, estimate_n_max, estimate_n_max_from_patch,
+from .pickers import (estimate_patch_size, radial_profile, autocorrelation, estimate_n_max, estimate_n_max_from_patch,
                       _get_cumulative_energy)
 from .consumers import pca
 
 __all__ = ["ZPs", "zmoments", "construct_rot_maps_matrix", "construct_complex_matrix",
            "construct_real_matrix", "nm2j", "nm2j_complex", "check_array1d",
-           "estimate_patch_size", "radial_profile", "estimate_n_max", "estimate_n_max_from_patch", "pca"]
+           "estimate_patch_size", "radial_profile", "autocorrelation", "estimate_n_max", "estimate_n_max_from_patch", "pca"]

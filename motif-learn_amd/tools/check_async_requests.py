@@ -7,8 +7,10 @@ late table data, was a memory-aperture fault in round 3).
 
   check_async_requests.py file.s [kernel-name-substring]      exit 1 and a listing if any hazard exists
 
-Walks the control-flow graph of every kernel in the assembly (hipcc -S --cuda-device-only): the set of in-flight destination
-registers is propagated along fall-through and branch edges to a fixed point."""
+Walks the control-flow graph of every kernel in the assembly (hipcc -S --cuda-device-only): the QUEUE of operations that may
+still be outstanding on the LGKM counter is propagated along fall-through and branch edges; s_waitcnt lgkmcnt(N) with N > 0
+retires what the in-order return of LDS reads guarantees (zk_frame_strip3_kernel waits for a pixel pair with the next pair
+still in flight), lgkmcnt(0) everything."""
 import re
 import sys
 
@@ -67,46 +69,83 @@ def check(name, lines):
         t = t.split(";")[0].strip()
         parts = re.split(r"[ ,\t]+", t)
         ins.append((parts[0], parts[1:], in_asm, t))
+    # State = the queue of LGKM operations that may still be outstanding, oldest first: (kind, destination registers, hand-issued).
+    # LDS reads return in order, scalar loads in any order, and s_waitcnt lgkmcnt(N) returns when at most N are outstanding:
+    #   an LDS entry is certainly complete iff more than N LDS entries stand at or behind it in the queue (were it
+    #   outstanding, all of those would be too); a scalar entry only after lgkmcnt(0).
+    # The compiler's own loads count (they share the counter) but only hand-issued destinations are checked: the compiler
+    # places waits for what it issued itself.  Every distinct state reaching an instruction is followed (bounded).
     n = len(ins)
-    state_in = [None] * n
-    work = [(0, frozenset())]
+    seen_states = [set() for _ in range(n)]
+    work = [(0, ())]
     hazards = {}
+
+    def in_flight(q):
+        out = set()
+        for kind, rg, hand in q:
+            if hand:
+                out |= rg
+        return out
+
     while work:
-        i, fl = work.pop()
+        i, q = work.pop()
         while i < n:
-            if state_in[i] is not None and fl <= state_in[i]:
+            if q in seen_states[i]:
                 break
-            fl = fl | (state_in[i] or frozenset())
-            state_in[i] = fl
+            if len(seen_states[i]) > 256:
+                hazards[i] = "too many distinct request states reach this instruction (checker limit)"
+                break
+            seen_states[i].add(q)
+            fl = in_flight(q)
             op, args, in_asm, text = ins[i]
-            if in_asm and (op.startswith("s_load") or op.startswith("ds_read")):
+            is_lds_read = op.startswith("ds_read")
+            is_smem = op.startswith("s_load") or op.startswith("s_buffer_load") or op.startswith("s_memtime") or op.startswith("s_memrealtime")
+            if is_lds_read or is_smem:
                 for a in args[1:]:
                     if regs(a) & fl:
                         hazards[i] = f"request READS in-flight registers: {text}"
-                fl = fl | regs(args[0])
-            elif op == "s_waitcnt" and "lgkmcnt(0)" in text:
-                fl = frozenset()
+                if regs(args[0]) & fl:
+                    hazards[i] = f"request WRITES in-flight registers: {text}"
+                q = q + (("lds" if is_lds_read else "smem", frozenset(regs(args[0])), bool(in_asm)),)
+            elif op.startswith(("ds_write", "ds_add", "ds_swizzle", "ds_bpermute", "ds_permute", "s_sendmsg")) or op.startswith("ds_"):
+                for a in args:
+                    if regs(a) & fl:
+                        hazards[i] = f"READS in-flight {sorted(regs(a) & fl)[:4]}: {text}"
+                        break
+                q = q + (("lds", frozenset(), False),)   # occupies the counter, returns in order with the reads
+            elif op == "s_waitcnt":
+                m = re.search(r"lgkmcnt\((\d+)\)", text)
+                if m:
+                    N = int(m.group(1))
+                    lds_behind = 0
+                    keep = []
+                    for kind, rg, hand in reversed(q):
+                        if kind == "lds":
+                            lds_behind += 1
+                            if lds_behind <= N:
+                                keep.append((kind, rg, hand))
+                        elif N > 0:
+                            keep.append((kind, rg, hand))
+                    q = tuple(reversed(keep))
             elif not op.startswith(NO_DEST) and args:
                 dst = regs(args[0])
-                if op.startswith("v_cmp") and len(args) > 2 and not op.endswith("_e32"):
-                    pass
                 if dst & fl:
                     hazards[i] = f"WRITES in-flight {sorted(dst & fl)[:4]}: {text}"
                 for a in args[1:]:
                     if regs(a) & fl:
                         hazards[i] = f"READS in-flight {sorted(regs(a) & fl)[:4]}: {text}"
                         break
-            elif op.startswith(("global_store", "ds_write", "v_cmpx", "s_cmp")):
+            elif op.startswith(("global_store", "v_cmpx", "s_cmp")):
                 for a in args:
                     if regs(a) & fl:
                         hazards[i] = f"READS in-flight {sorted(regs(a) & fl)[:4]}: {text}"
                         break
             if op in ("s_branch", "s_setpc_b64"):
                 if op == "s_branch" and args[0] in labels:
-                    work.append((labels[args[0]], fl))
+                    work.append((labels[args[0]], q))
                 break
             if op.startswith("s_cbranch") and args and args[-1] in labels:
-                work.append((labels[args[-1]], fl))
+                work.append((labels[args[-1]], q))
             if op == "s_endpgm":
                 break
             i += 1

@@ -520,6 +520,32 @@ def test_strip_and_one_output_dense_kernels_agree(native, zo):
         assert np.abs(strip - single).max() > 0   # two different kernels ran (different summation orders)
 
 
+@pytest.mark.parametrize("n_max,size,shape,dtype", [(8, 32, (70, 131), np.float32), (8, 32, (33, 64), np.float64),
+                                                    (6, 24, (41, 66), np.float32), (4, 16, (17, 200), np.float32),
+                                                    (8, 8, (9, 70), np.float64), (7, 30, (64, 64), np.float32)])
+def test_strip_kernel_with_the_table_in_vgpr_lanes(native, zo, n_max, size, shape, dtype, monkeypatch):
+    """ZK_STRIP_V3=1 (opt-in, zk_frame_strip3_kernel: even windows <= 32 px, n_max <= 8): the x table in VGPR lanes read through
+    v_fmac_f64_dpp row_newbcast, one sweep per frame row, LDS requests two blocks ahead.  Same moments as the default
+    strip kernel up to the summation order, both against the oracle; ragged shapes and the zero-padded borders included."""
+    rng = np.random.default_rng(size * 7 + n_max)
+    z = _zps(n_max, size)
+    plan = z._device_plan()
+    img = (rng.random(shape) - 0.5).astype(dtype)
+    ref = zo.moments_frame_direct(img, z.polynomials)
+    plan.set_path(native.PATH_SEPARABLE)
+    try:
+        base = plan.transform_frame(img)
+        monkeypatch.setenv("ZK_STRIP_V3", "1")
+        lanes = plan.transform_frame(img)
+    finally:
+        monkeypatch.delenv("ZK_STRIP_V3", raising=False)
+        plan.set_path(native.PATH_AUTO)
+    rel_close(base, ref)
+    rel_close(lanes, ref)
+    assert np.abs(base - lanes).max() > 0         # two different kernels ran
+    np.testing.assert_allclose(lanes, base, rtol=0, atol=1e-13 * np.abs(ref).max())
+
+
 def test_zero_and_constant_inputs(native):
     z = _zps(8, 32)
     assert not z.transform(np.zeros((5, 32, 32), np.float32)).data.any()
