@@ -66,20 +66,31 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------
 # self-launch: one child process per GPU, started before anything in this process touches the GPU
 # ---------------------------------------------------------------------------------------------------------
+def is_rehearsal(env):
+    """N RCCL ranks on ONE GPU (ZK_BENCH_ONE_DEVICE=1, a test aid): the only case in which a rank is given an NCCL_HOSTID and
+    RCCL's peer-to-peer / shared-memory transports are switched off.  On a real node (one GPU per rank) nothing of the
+    kind is set: RCCL picks its transports itself, and `allgather.transport` in the line says which."""
+    return bool(env.get("ZK_BENCH_ONE_DEVICE")) and env.get("ZK_BENCH_BACKEND", "rccl") == "rccl" and not env.get("ZK_BENCH_SAME_HOSTID")
+
+
+def rank_env(base, rank, world, port):
+    """Environment of child `rank` of the self-launched job (tests/test_bench_env_cpu.py)."""
+    env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if is_rehearsal(base):
+        # rehearsal of N RCCL ranks on ONE GPU: a host id per rank (mtflearn_amd.distributed.one_gpu_rank_env)
+        from mtflearn_amd.distributed import one_gpu_rank_env
+        env = one_gpu_rank_env(rank, env)
+    return env
+
+
 def launch(args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    one_device = bool(os.environ.get("ZK_BENCH_ONE_DEVICE"))
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if one_device and os.environ.get("ZK_BENCH_BACKEND", "rccl") == "rccl" and not os.environ.get("ZK_BENCH_SAME_HOSTID"):
-            # rehearsal of N RCCL ranks on ONE GPU: a host id per rank (mtflearn_amd.distributed.one_gpu_rank_env)
-            from mtflearn_amd.distributed import one_gpu_rank_env
-            env = one_gpu_rank_env(r, env)
+        env = rank_env(os.environ, r, args.gpus, port)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
     code, kill_at = 0, None
@@ -317,11 +328,17 @@ def worker(args):
     from mtflearn_amd import distributed as D
     from mtflearn_amd.synthetic import honeycomb_frame
 
-    if (os.environ.get("ZK_BENCH_ONE_DEVICE") and backend == "rccl" and world > 1 and "NCCL_HOSTID" not in os.environ
-            and not os.environ.get("ZK_BENCH_SAME_HOSTID")):
+    rehearsal = is_rehearsal(os.environ) and world > 1
+    if rehearsal and "NCCL_HOSTID" not in os.environ:
         # the one-GPU rehearsal under an outside launcher (python -m torch.distributed.run ... bench.py --gpus N, the driver's
         # form): the launcher did not give the ranks their host ids, so each takes its own before RCCL is initialised
         os.environ.update(D.one_gpu_rank_env(rank, {}))
+    rccl_log = None
+    if world > 1 and backend == "rccl":
+        # which transport RCCL connects the ranks over goes into the line (allgather.transport): INFO output of its INIT
+        # phase into a file of this rank's own, parsed after the gathers have run
+        os.environ.update(D.rccl_debug_env(rank))
+        rccl_log = os.environ.get("NCCL_DEBUG_FILE")
     dead = Deadman(rank, world, json_fd, args)
     limit = float(os.environ.get("ZK_BENCH_PHASE_TIMEOUT", os.environ.get("ZK_BENCH_SIDE_TIMEOUT", "420")))
     comm = None
@@ -432,7 +449,24 @@ def worker(args):
             comm.join(D._current_stream_ptr(full))
         fence()
         alone_ms = comm.max_over_ranks((time.perf_counter() - t1) / 3 * 1e3)
+        # what RCCL connected the ranks over, from every rank's own log (P2P/IPC = xGMI inside a node; NET/Socket in the
+        # one-GPU rehearsal), and how many ranks the communicator holds
+        counts = {}
+        try:
+            if rccl_log:
+                with open(rccl_log.replace("%h", socket.gethostname()).replace("%p", str(os.getpid())), errors="replace") as fh:
+                    counts = D.rccl_transport_summary(fh.read())
+        except OSError:
+            counts = {}
+        all_counts = [json.loads(b.decode()) for b in comm.allgather_host(json.dumps(counts).encode().ljust(256))]
+        ranks_seen = int(comm.ranks_seen()) if backend == "rccl" else world
+        link_GBps = rl.XGMI_LINKS * rl.XGMI_LINK_GBS
+        received = (world - 1) * n_local * n_poly * 8 / (alone_ms * 1e-3) / 1e9
         gather = {"verified": ok, "own_block_equals_recomputation": own_ok, "ms_alone": alone_ms, "chunks": args.gather_chunks,
+                  "transport": D.describe_transport(all_counts, rehearsal) if backend == "rccl" else "gloo (rehearsal)",
+                  "transport_channels_per_rank": all_counts, "ranks_seen": ranks_seen,
+                  "xgmi_bound_GBps_per_rank": link_GBps,
+                  "frac_of_xgmi_bound": received / link_GBps,
                   "backend": {"rccl": "rccl (zk_allgather_rows in libzernike_hip.so)", "gloo": "gloo (rehearsal)"}.get(backend, backend),
                   "ms_per_step_with_allgather": el_gather / args.steps * 1e3,
                   "value_with_allgather": n_total / (el_gather / args.steps),

@@ -529,6 +529,10 @@ class Comm:
             raise ValueError("Comm needs one of path=, port= or unique_id=")
         self._h, self._lib = handle, lib
 
+    def ranks_seen(self):
+        """World size as the communicator inside the library holds it (``zk_comm_world``)."""
+        return int(self._lib.zk_comm_world(self._h))
+
     @staticmethod
     def unique_id():
         buf = ctypes.create_string_buffer(Comm.ID_BYTES)

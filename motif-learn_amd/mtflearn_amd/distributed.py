@@ -61,6 +61,49 @@ def one_gpu_rank_env(rank, base=None):
     return env
 
 
+def rccl_debug_env(rank, base=None, directory="/tmp"):
+    """Environment additions that make RCCL write, per rank, which transport it connected every channel over
+    (``NCCL_DEBUG=INFO`` restricted to the connection subsystems, into a file of this rank's own): what
+    :func:`rccl_transport_summary` reads afterwards.  A level below INFO (unset, ``VERSION``, ``WARN`` -- the image exports
+    ``VERSION``) is raised to INFO; a caller's ``INFO`` / ``TRACE`` run, its subsystem list and its log file are left alone."""
+    import os
+    env = {}
+    have = os.environ if base is None else base
+    if have.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
+        env["NCCL_DEBUG"] = "INFO"
+        if "NCCL_DEBUG_SUBSYS" not in have:
+            env["NCCL_DEBUG_SUBSYS"] = "INIT,P2P,NET,SHM"
+    if "NCCL_DEBUG_FILE" not in have:
+        env["NCCL_DEBUG_FILE"] = os.path.join(directory, f"zk_rccl_{os.getpid()}_rank{rank}.log")
+    return env
+
+
+def rccl_transport_summary(log_text):
+    """Channels per transport from an RCCL INFO log: the ``Channel NN : a[dev] -> b[dev] via P2P/IPC`` /
+    ``... [send] via NET/Socket/0`` lines librccl prints when it connects a channel.  Returns ``{transport: count}``, e.g.
+    ``{"P2P/IPC": 112}`` on an xGMI node or ``{"NET/Socket": 24}`` for ranks that met over sockets."""
+    import re
+    counts = {}
+    for m in re.finditer(r"Channel \d+(?:/\d+)? *: *\d+\[[^\]]*\] *-> *\d+\[[^\]]*\](?: \[(?:send|receive)\])? via ([A-Za-z0-9]+(?:/[A-Za-z]+)?)",
+                         log_text):
+        counts[m.group(1)] = counts.get(m.group(1), 0) + 1
+    return counts
+
+
+def describe_transport(per_rank_counts, rehearsal=False):
+    """One string for the bench line from every rank's ``rccl_transport_summary``: the transports seen, most used first --
+    ``"P2P/IPC"`` when every channel of every rank is peer-to-peer (xGMI inside a node), ``"NET/Socket (rehearsal)"``
+    for the one-GPU rehearsal, ``"unknown (no channel lines in the RCCL log)"`` when nothing could be parsed."""
+    total = {}
+    for c in per_rank_counts:
+        for k, v in c.items():
+            total[k] = total.get(k, 0) + v
+    if not total:
+        return "unknown (no channel lines in the RCCL log)"
+    names = " + ".join(k for k, _ in sorted(total.items(), key=lambda kv: -kv[1]))
+    return names + (" (rehearsal)" if rehearsal else "")
+
+
 def _chunk_bounds(padded: int, n_chunks: int):
     """Cut ``[0, padded)`` into at most ``n_chunks`` consecutive non-empty windows (same on every rank)."""
     n_chunks = max(1, min(int(n_chunks), padded)) if padded > 0 else 1
@@ -213,6 +256,9 @@ class RcclComm:
 
     def join(self, stream=0):
         self._c.join(stream)
+
+    def ranks_seen(self):
+        return self._c.ranks_seen()
 
     def allgather_host(self, payload: bytes):
         return self._c.allgather_host(payload)

@@ -6,6 +6,8 @@ from __future__ import annotations
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 achievable)
+XGMI_LINKS = 7                 # task statement / SURVEY 5: point-to-point xGMI, 7 links x ~153 GB/s per GPU
+XGMI_LINK_GBS = 153.0
 FP64_VECTOR_PEAK_TF = 78.6     # public datasheet figure (not in the local guide); 62 TF measured on register
                                # operands, 49-55 TF with SGPR-fed v_fma_f64 (profiles/r01_micro_sfma.txt)
 
