@@ -911,6 +911,41 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
         del out_f
         torch.cuda.empty_cache()
 
+    # ---- moments at key points of the resident frame (reference features/_keypoint.py:60-78 + _zps.py:146-157) ----
+    if not args.no_dense and plan.supports(_native.OP_POINTS, _native.ZK_F32):
+        from ctypes import c_void_p
+        n_pts = 1 << 20
+        rng = np.random.default_rng(0)
+        pts = rng.integers(K // 2, H - K // 2, size=(n_pts, 2)).astype(np.int32)
+        out_p = torch.empty((n_pts, n_poly), dtype=torch.float64, device=dev)
+        flops = rl.sep_flops_per_unit(z.polynomials[0], n_max)
+        disk_px = int(np.count_nonzero(z.polynomials[0]))
+        sec = {"workload": f"{n_pts} key points on the resident {H}x{H} frame -> ({n_pts}, {n_poly}) float64 moments, no (N, {K}, {K}) batch in memory; "
+                           f"points bucketed on the device by frame row x 256 columns (bit-identical to the caller's order)",
+               "kernel": "zk_points_sep_kernel (+ zk_points_hist / _scan / _scatter)", "fp64_flops_per_point": flops,
+               "l2_gather_bytes_per_point": disk_px * 4, "algorithmic_hbm_bytes_per_point": 8 + 8 * n_poly}
+        for order in ("random", "sorted"):
+            d_pts = torch.from_numpy(pts if order == "random" else pts[np.lexsort((pts[:, 0], pts[:, 1]))]).to(dev)
+            run = lambda: _native.check(plan._lib.zk_transform_points_dev(plan._h, c_void_p(f_dev.data_ptr()), _native.ZK_F32, H, H,
+                                                                          c_void_p(d_pts.data_ptr()), n_pts, c_void_p(out_p.data_ptr()),
+                                                                          c_void_p(D._current_stream_ptr(out_p))), "zk_transform_points_dev")
+            t = _profiled(plan, run)
+            # the whole call, bucketing kernels included (they carry no profiling bracket): stream events around 10 calls
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                run()
+            e1.record()
+            torch.cuda.current_stream().synchronize()
+            call_ms = e0.elapsed_time(e1) / 10
+            sec[order] = {"points_per_s": n_pts / (call_ms * 1e-3), "call_ms": call_ms, "moment_kernel_ms": t.ms, **_spread(t),
+                          "roofline": _fp64_roofline(n_pts * flops, n_pts * (8 + 8 * n_poly), t.ms, t["shader_clock_ghz"]),
+                          "l2_gather_GBps": n_pts * disk_px * 4 / (t.ms * 1e-3) / 1e9,
+                          "l2_gather_frac_of_17_TBps": n_pts * disk_px * 4 / (t.ms * 1e-3) / 1e9 / 17000.0}
+        result["key_points"] = sec
+        del out_p, d_pts
+        torch.cuda.empty_cache()
+
     # ---- configs[3], one GPU's share: 8 frames of 2048^2, dense moments of each into (8, N_poly, H, W) ----------------
     if not args.no_multi_frame:
         per_rank = 8

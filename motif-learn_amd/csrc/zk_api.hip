@@ -160,6 +160,7 @@ extern "C" void zk_plan_destroy(zk_plan* p) {
   zk_host_release(p);
   if (p->d_scratch) (void)hipFree(p->d_scratch);
   if (p->d_gather) (void)hipFree(p->d_gather);
+  if (p->d_points_tmp) (void)hipFree(p->d_points_tmp);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }

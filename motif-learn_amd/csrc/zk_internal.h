@@ -69,6 +69,8 @@ struct zk_plan {
   size_t host_chunk = 0;                // bytes of input + output per chunk; 0 = default
   void* d_gather = nullptr;      // key points without the key-point kernel: windows cut on the device
   size_t d_gather_bytes = 0;
+  void* d_points_tmp = nullptr;  // key points: bucket histogram, cursors and the index list in bucket order (zk_sep_points.hip)
+  size_t d_points_tmp_bytes = 0;
   double* d_scratch = nullptr;   // class-pass batch kernels (n_max > 16): [n_poly][chunk] planes
   size_t d_scratch_bytes = 0;
   // distance in doubles between consecutive output planes of the dense / maps kernels; 0 = compact

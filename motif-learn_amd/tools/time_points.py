@@ -13,7 +13,11 @@ n_max = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 z = ZPs(n_max, 32); plan = z._device_plan()
 img = torch.from_numpy(honeycomb_frame(2048, seed=1)).cuda()
 rng = np.random.default_rng(0)
-for n_pts, kind in [(1 << 20, "random"), (1 << 20, "sorted"), (100000, "random")]:
+for n_pts, kind, bucket in [(1 << 20, "random", True), (1 << 20, "random", False), (1 << 20, "sorted", True), (1 << 20, "sorted", False),
+                            (100000, "random", True), (100000, "random", False)]:
+    os.environ.pop("ZK_POINTS_NO_BUCKET", None)
+    if not bucket:
+        os.environ["ZK_POINTS_NO_BUCKET"] = "1"
     pts = rng.integers(16, 2048 - 16, size=(n_pts, 2)).astype(np.int32)
     if kind == "sorted":
         pts = pts[np.lexsort((pts[:, 0], pts[:, 1]))]
@@ -27,4 +31,11 @@ for n_pts, kind in [(1 << 20, "random"), (1 << 20, "sorted"), (100000, "random")
         run()
     torch.cuda.synchronize()
     k, ms = plan.profile_read(); plan.profile(False)
-    print(f"{n_pts:8d} {kind:6s} points: {ms / k:7.3f} ms  {n_pts / (ms / k) / 1e3:8.1f} M points/s")
+    per_call = ms * (k // 5 if k >= 5 else 1) / k      # the bucketing kernels are not profiled launches: HIP events around the moment kernel only
+    print(f"{n_pts:8d} {kind:6s} points, {'bucketed' if bucket else 'caller order'}: moment kernel {ms / k:7.3f} ms  {n_pts / (ms / k) / 1e3:8.1f} M points/s", flush=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(5):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    print(f"         whole call (default stream, incl. bucketing): {e0.elapsed_time(e1) / 5:7.3f} ms  {n_pts / (e0.elapsed_time(e1) / 5) / 1e3:8.1f} M points/s")

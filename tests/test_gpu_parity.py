@@ -159,7 +159,7 @@ def test_moments_at_key_points(native, zo):
         ref = zo.moments_patches(patches, z.polynomials)
         got = z.transform_at(frame, pts)
         assert got.data.shape == ref.shape and got.patch_size == size
-        rel_close(got.data, ref, atol_scale=3e-7 if n_max > 20 else 1e-8 if n_max > 16 else 1e-10 if n_max > 12 else 1e-11 if n_max > 10 else 1e-12)
+        rel_close(got.data, ref, atol_scale=_floor("auto", n_max))
     z = _zps(8, 32)
     frame = rng.random((64, 64)).astype(np.float32)
     edge = z.transform_at(frame, [[0, 0], [63, 63], [5, 60]]).data                       # zero padding outside
@@ -172,8 +172,50 @@ def test_moments_at_key_points(native, zo):
     edge18 = z18.transform_at(frame, [[0, 0], [63, 63], [5, 60], [30, 31]]).data
     padded = np.pad(frame, 24)
     ref18 = np.array([padded[y + 12:y + 36, x + 12:x + 36] for x, y in [(0, 0), (63, 63), (5, 60), (30, 31)]])
-    rel_close(edge18, zo.moments_patches(ref18, z18.polynomials), atol_scale=1e-8)
+    rel_close(edge18, zo.moments_patches(ref18, z18.polynomials), atol_scale=1e-11)
     assert z.transform_at(frame, np.empty((0, 2))).data.shape == (0, 45)
+
+
+@pytest.mark.parametrize("n_max,size,n_points,order", [(8, 32, 100000, "random"), (8, 32, 70001, "sorted"), (12, 40, 30000, "random"),
+                                                       (14, 32, 9000, "clustered"), (6, 16, 4096, "random"), (8, 32, 4095, "random")])
+def test_key_points_in_bucket_order_are_bit_identical(native, zo, n_max, size, n_points, order, monkeypatch):
+    """Large point lists go through a counting sort into buckets of one frame row x 256 columns (zk_sep_points.hip) and the
+    moment kernel takes them in bucket order, writing every result to the point's own row: the SAME bits as the kernel in the
+    caller's order (ZK_POINTS_NO_BUCKET=1), whatever the order -- random, sorted, heavy duplicates, points outside the frame --
+    and a sample against the oracle on the reference's slicing (features/_keypoint.py:60-78)."""
+    import torch
+    rng = np.random.default_rng(n_points)
+    H, W = 300, 1100                                                                 # five 256-column buckets per row
+    frame = rng.random((H, W)).astype(np.float32)
+    pts = np.column_stack([rng.integers(-20, W + 20, n_points), rng.integers(-20, H + 20, n_points)]).astype(np.int32)
+    if order == "sorted":
+        pts = pts[np.lexsort((pts[:, 0], pts[:, 1]))]
+    if order == "clustered":
+        pts[:, 0] = 500 + pts[:, 0] % 7                                              # thousands of points in two buckets, duplicates
+        pts[:, 1] = 100 + pts[:, 1] % 3
+    z = _zps(n_max, size)
+    plan = z._device_plan()
+    d_img, d_pts = torch.from_numpy(frame).cuda(), torch.from_numpy(pts).cuda()
+    out = [torch.full((n_points, len(z.n)), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+    from ctypes import c_void_p
+    for k, env in enumerate((None, "1")):
+        if env:
+            monkeypatch.setenv("ZK_POINTS_NO_BUCKET", env)
+        else:
+            monkeypatch.delenv("ZK_POINTS_NO_BUCKET", raising=False)
+        native.check(plan._lib.zk_transform_points_dev(plan._h, c_void_p(d_img.data_ptr()), native.ZK_F32, H, W, c_void_p(d_pts.data_ptr()),
+                                                       n_points, c_void_p(out[k].data_ptr()), None), "zk_transform_points_dev")
+        torch.cuda.synchronize()
+    monkeypatch.delenv("ZK_POINTS_NO_BUCKET", raising=False)
+    a, b = out[0].cpu().numpy(), out[1].cpu().numpy()
+    assert not np.isnan(a).any()
+    np.testing.assert_array_equal(a, b)
+    pick = rng.choice(n_points, 200, replace=False)
+    s1, s2 = size // 2, size - size // 2
+    padded = np.pad(frame, size + 20)
+    o = size + 20
+    win = np.array([padded[y + o - s1:y + o + s2, x + o - s1:x + o + s2] for x, y in pts[pick]])
+    rel_close(a[pick], zo.moments_patches(win, z.polynomials), atol_scale=_floor("auto", n_max))
 
 
 def test_symmetry_of_moment_rows(native, golden, zo):
