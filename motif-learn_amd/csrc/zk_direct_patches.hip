@@ -23,6 +23,7 @@
 //   the functions are done CH at a time: one launch per chunk over the same patches (the patches come from L2 / Infinity Cache
 //   after the first chunk); results go straight into the (N, n_poly) rows (16 consecutive functions per 128-B segment).
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -73,7 +74,7 @@ int upload(T** dst, const std::vector<T>& src) {
 }
 
 // one chunk of CH functions (columns col0 .. col0 + n_live - 1 of the result) for all patches
-template <typename TIN>
+template <typename TIN, bool ROLL>
 __global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __restrict__ in, double* __restrict__ out,
                                                                  const zk_direct_unit* __restrict__ units,
                                                                  const double* __restrict__ tab, int n_units, int col0, int n_live,
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __re
   typedef double v4d __attribute__((ext_vector_type(4)));
   constexpr int PXG = 16 / sizeof(TIN);  // pixels per 16-B granule: 4 (float32) or 2 (float64)
   constexpr int UP = 4 * PXG;            // pixels per run
-  constexpr int NSTEP = UP;              // steps per unit: 4 runs x UP slots / 4
+  static_assert(UP == 4 * PXG, "a run = PXG steps of 4 slots");
   extern __shared__ __attribute__((aligned(16))) float lds[];  // one 16-KiB slab per wave
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -130,35 +131,83 @@ __global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __re
     for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = v4d{0.0, 0.0, 0.0, 0.0};
   const double* __restrict__ tlane = tab + (size_t)kr * CH + li;  // this lane's column of a step's four table rows
 
-  issue(0);
+  // Rolling re-arm (round 4): a run's 4-KiB piece of the slab is free as soon as its PXG steps have read it, so the next unit's
+  // run goes into it at once and has the other three runs' arithmetic (12 steps x 24 MFMAs) to land -- the DMA latency that the
+  // whole-slab form exposed once per unit is hidden.  Vector-memory operations complete in order: at the start of a run the only
+  // younger ones are the four DMA instructions issued at the end of the previous run, so vmcnt(4) says "this run has landed".
+  auto issue_run = [&](int u, int rho) {
+    const int ro = utab[8 * u + rho];
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg)
+      __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(wbase + (poff[pg] + ro)), ZK_LDS_PTR(lds + wave * 4096 + (rho * 4 + pg) * 256), 16,
+                                       0, 0);
+  };
+  (void)issue;
+#pragma unroll
+  for (int rho = 0; rho < 4; ++rho) issue_run(0, rho);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (!ROLL) {  // the round-3 form: the whole slab re-armed after the unit's last step (ZK_DIRECT_NO_ROLL=1 / 0 forces either)
+    for (int u = 0; u < n_units; ++u) {
+      const int steps = utab[8 * u + 4];
+      const unsigned own_lo = (unsigned)utab[8 * u + 5], own_hi = (unsigned)utab[8 * u + 6];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const double* __restrict__ tu = tlane + (size_t)u * (4 * UP) * CH;
+#pragma unroll 2
+      for (int st = 0; st < 4 * PXG; ++st) {
+        if (!((steps >> st) & 1)) continue;
+        const int rho = st / PXG;
+        const int x = 4 * (st % PXG) + kr;
+        const int gsl = ((x / PXG + prot) & 3) * PXG + x % PXG;
+        double av[4], bv[FB];
+        const bool mine = (((st < 8 ? own_lo : own_hi) >> (4 * (st & 7) + kr)) & 1u) != 0;
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+          const double v = (double)ws[rho * 64 * UP + pbase[pb] + gsl];
+          av[pb] = mine ? v : 0.0;
+        }
+        const double* __restrict__ tr = tu + (size_t)st * 4 * CH;
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) bv[fb] = tr[16 * fb];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+          for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb], bv[fb], acc[pb][fb], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (u + 1 < n_units) issue(u + 1);
+    }
+  } else
   for (int u = 0; u < n_units; ++u) {
     const int steps = utab[8 * u + 4];
     const unsigned own_lo = (unsigned)utab[8 * u + 5], own_hi = (unsigned)utab[8 * u + 6];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of unit u has landed
     const double* __restrict__ tu = tlane + (size_t)u * (4 * UP) * CH;
-#pragma unroll 2
-    for (int st = 0; st < NSTEP; ++st) {
-      if (!((steps >> st) & 1)) continue;  // wave-uniform: four zero rows
-      const int rho = st / PXG;                                      // run of this step
-      const int x = 4 * (st % PXG) + kr;                             // slot inside the run
-      const int gsl = ((x / PXG + prot) & 3) * PXG + x % PXG;        // its element inside the patch's (rotated) 64 B
-      double av[4], bv[FB];
-      const bool mine = (((st < 8 ? own_lo : own_hi) >> (4 * (st & 7) + kr)) & 1u) != 0;
 #pragma unroll
-      for (int pb = 0; pb < 4; ++pb) {
-        const double v = (double)ws[rho * 64 * UP + pbase[pb] + gsl];
-        av[pb] = mine ? v : 0.0;
+    for (int rho = 0; rho < 4; ++rho) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // run rho of unit u has landed (issued a unit ago)
+#pragma unroll
+      for (int sr = 0; sr < PXG; ++sr) {
+        const int st = rho * PXG + sr;
+        if (!((steps >> st) & 1)) continue;  // wave-uniform: four zero rows
+        const int x = 4 * sr + kr;                                     // slot inside the run
+        const int gsl = ((x / PXG + prot) & 3) * PXG + x % PXG;        // its element inside the patch's (rotated) 64 B
+        double av[4], bv[FB];
+        const bool mine = (((st < 8 ? own_lo : own_hi) >> (4 * (st & 7) + kr)) & 1u) != 0;
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+          const double v = (double)ws[rho * 64 * UP + pbase[pb] + gsl];
+          av[pb] = mine ? v : 0.0;
+        }
+        const double* __restrict__ tr = tu + (size_t)st * 4 * CH;
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) bv[fb] = tr[16 * fb];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+          for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb], bv[fb], acc[pb][fb], 0, 0, 0);
       }
-      const double* __restrict__ tr = tu + (size_t)st * 4 * CH;
-#pragma unroll
-      for (int fb = 0; fb < FB; ++fb) bv[fb] = tr[16 * fb];
-#pragma unroll
-      for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-        for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb], bv[fb], acc[pb][fb], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this run's piece of the slab is no longer read
+      if (u + 1 < n_units) issue_run(u + 1, rho);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is no longer read
-    if (u + 1 < n_units) issue(u + 1);
   }
   // D layout: lane holds rows (patch-in-block) kr + 4 q, column (function-in-block) li
 #pragma unroll
@@ -193,9 +242,15 @@ int launch_t(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStre
       const int n_live = std::min(CH, p->n_poly - c * CH);
       int rc = zk_prof_begin(p, s);
       if (rc) return rc;
-      hipLaunchKernelGGL(zk_patch_direct_kernel<TIN>, dim3(blocks), dim3(256), 65536, s, src, out + first * p->n_poly, t.d_units,
-                         t.d_tab + c * tab_chunk, t.n_units, c * CH, n_live, p->n_poly, (long long)n,
-                         (int)(patch_elems * sizeof(TIN)));
+      // whole-slab re-arm when every SIMD holds two waves (the other wave hides the DMA wait: 0.64-0.84 of the FP64 peak,
+      // 2 % ahead of the rolling form); rolling re-arm for batches that leave CUs half empty (+7 %): profiles/r04_direct_batch.txt
+      const char* force = getenv("ZK_DIRECT_NO_ROLL");
+      if (force ? *force == '1' : blocks >= 2u * (unsigned)p->n_cu)
+        hipLaunchKernelGGL((zk_patch_direct_kernel<TIN, false>), dim3(blocks), dim3(256), 65536, s, src, out + first * p->n_poly, t.d_units,
+                           t.d_tab + c * tab_chunk, t.n_units, c * CH, n_live, p->n_poly, (long long)n, (int)(patch_elems * sizeof(TIN)));
+      else
+        hipLaunchKernelGGL((zk_patch_direct_kernel<TIN, true>), dim3(blocks), dim3(256), 65536, s, src, out + first * p->n_poly, t.d_units,
+                           t.d_tab + c * tab_chunk, t.n_units, c * CH, n_live, p->n_poly, (long long)n, (int)(patch_elems * sizeof(TIN)));
       ZK_HIP(hipGetLastError());
       if ((rc = zk_prof_end(p, s))) return rc;
     }
