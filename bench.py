@@ -398,7 +398,7 @@ def worker(args):
             step()
         fence()
         dt = time.perf_counter() - t0
-        per_launch = plan.profile_read_launches()
+        per_launch = plan.profile_read_launches(cap=max(65536, args.steps * (args.gather_chunks + 2)))
         plan.profile(False)
         launches, kernel_ms = len(per_launch), float(sum(per_launch))
         if comm is not None:

@@ -490,6 +490,7 @@ int zk_hbm_probe(int device, const void* src_dev, void* dst_dev, int64_t bytes, 
  * stop is called or `max_ms` (<= 2000) have passed; stop returns the mean clock in GHz over the `ms` the wave was resident.
  * The FP64-bound kernels of this library run at 1.7-2.2 GHz of the nominal 2.4 (power management), so their rates are stated
  * against the measured clock as well as the nominal one. */
+long long zk_debug_strip3_launches(void);  /* launches of the opt-in dense kernel zk_frame_strip3_kernel (ZK_STRIP_V3=1) so far: tests */
 typedef struct zk_clock_monitor zk_clock_monitor;
 int zk_clock_monitor_start(int device, double max_ms, zk_clock_monitor** out);
 int zk_clock_monitor_stop(zk_clock_monitor* monitor, double* ghz_out, double* ms_out);

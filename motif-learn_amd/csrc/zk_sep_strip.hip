@@ -633,9 +633,12 @@ int launch_strip2(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0
   });
 }
 
+static long long g_strip3_launches = 0;  // (tests: the opt-in kernel really ran -- its moments equal the default kernel's bit for bit)
+
 template <int NMAX, typename T>
 int launch_strip3(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out, hipStream_t s) {
   const zk_sep_tables* t = p->sep;
+  ++g_strip3_launches;
   const size_t lds = (size_t)(p->size + 7) * t->tile_pitch * sizeof(double);
   auto kern = zk_frame_strip3_kernel<NMAX, T>;
   if (lds > 64 * 1024)
@@ -700,6 +703,8 @@ int launch_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int
 }
 
 }  // namespace
+
+extern "C" long long zk_debug_strip3_launches(void) { return g_strip3_launches; }
 
 bool zk_sep_strip_available(const zk_plan* p, int dtype) {
   (void)dtype;

@@ -138,6 +138,7 @@ SYMBOLS = {
     "zk_device_copy": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int]),
     "zk_device_synchronize": (c_int, [c_int]),
     "zk_hbm_probe": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_double)]),
+    "zk_debug_strip3_launches": (c_int64, []),
     "zk_clock_monitor_start": (c_int, [c_int, c_double, POINTER(c_void_p)]),
     "zk_clock_monitor_stop": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "zk_plan_profile": (c_int, [c_void_p, c_int]),

@@ -45,7 +45,7 @@ def main():
         fref = g[f"st_Zf_{tag}"]
         auto = [_native.PATH_NAMES[plan.best_path(0, _native.ZK_F32, 1 << 20)], _native.PATH_NAMES[plan.best_path(1, _native.ZK_F64)]]
         print(f"--- n_max {n_max} K {K} ({len(z.n)} moments)   ZK_PATH_AUTO: batch {auto[0]}, dense {auto[1]}")
-        n_t = 1 << 17 if K <= 40 else 1 << 16
+        n_t = 1 << 18 if K <= 48 else 1 << 17
         pt = frame.unfold(0, K, 5).unfold(1, K, 5).reshape(-1, K, K)[:n_t].contiguous()
         for path, name in _native.PATH_NAMES.items():
             line = f"  {name:10s}"

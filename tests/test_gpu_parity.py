@@ -567,25 +567,27 @@ def test_strip_and_one_output_dense_kernels_agree(native, zo):
                                                     (8, 8, (9, 70), np.float64), (7, 30, (64, 64), np.float32)])
 def test_strip_kernel_with_the_table_in_vgpr_lanes(native, zo, n_max, size, shape, dtype, monkeypatch):
     """ZK_STRIP_V3=1 (opt-in, zk_frame_strip3_kernel: even windows <= 32 px, n_max <= 8): the x table in VGPR lanes read through
-    v_fmac_f64_dpp row_newbcast, one sweep per frame row, LDS requests two blocks ahead.  Same moments as the default
-    strip kernel up to the summation order, both against the oracle; ragged shapes and the zero-padded borders included."""
+    v_fmac_f64_dpp row_newbcast, one sweep per frame row, LDS requests two blocks ahead.  The same operations in the same
+    order as the default strip kernel, so the same BITS; both against the oracle; ragged shapes and zero-padded borders."""
     rng = np.random.default_rng(size * 7 + n_max)
     z = _zps(n_max, size)
     plan = z._device_plan()
     img = (rng.random(shape) - 0.5).astype(dtype)
     ref = zo.moments_frame_direct(img, z.polynomials)
     plan.set_path(native.PATH_SEPARABLE)
+    count = native.load().zk_debug_strip3_launches
     try:
+        before = count()
         base = plan.transform_frame(img)
+        assert count() == before                  # the default kernel
         monkeypatch.setenv("ZK_STRIP_V3", "1")
         lanes = plan.transform_frame(img)
+        assert count() > before                   # the opt-in kernel really ran
     finally:
         monkeypatch.delenv("ZK_STRIP_V3", raising=False)
         plan.set_path(native.PATH_AUTO)
     rel_close(base, ref)
-    rel_close(lanes, ref)
-    assert np.abs(base - lanes).max() > 0         # two different kernels ran
-    np.testing.assert_allclose(lanes, base, rtol=0, atol=1e-13 * np.abs(ref).max())
+    np.testing.assert_array_equal(lanes, base)
 
 
 def test_zero_and_constant_inputs(native):
