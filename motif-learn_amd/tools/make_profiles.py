@@ -23,8 +23,8 @@ with open(os.path.join(P, f"{TAG}_kernel_stats_bench.csv"), "w") as f:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
     for r in rows:
         if "zk_" in r["Name"]:
-            w.writerow([r["Name"].replace("void (anonymous namespace)::", "").split("(")[0], r["Calls"], r["TotalDurationNs"],
-                        r["AverageNs"], r["MinNs"], r["MaxNs"]])
+            m = re.search(r"zk_\w+(?:<[^(]*>)?", r["Name"])
+            w.writerow([m.group(0) if m else r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"]])
 json.dump(json.loads(open(os.path.join(G, f"{TAG}_bench_under_rocprof.json")).read()),
           open(os.path.join(P, f"{TAG}_bench_line_under_rocprof.json"), "w"))
 
