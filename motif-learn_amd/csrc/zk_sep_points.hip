@@ -43,7 +43,22 @@ namespace {
 #define ZK_POINTS_W12 1
 #endif
 
-template <int NMAX, typename T>
+// Round 4 -- whole window rows as 16-byte loads (float32 frames, windows of 8 .. 64 px that lie inside the frame).  The
+// scalar-width form issues four 4-byte loads per quadrant pixel (740 per 32-px window): the kernel is bound by the rate of
+// vector-memory instructions, not by bytes (0.19 of the L2's gather rate, 0.14 of the FP64 peak).  A window row is K
+// contiguous floats, so a row pair is 4 QV unaligned `global_load_dwordx4` (QV = ceil(Q / 4): the left halves ascending, the
+// right halves from their far end so that register i of the pair (L, R) holds the mirror columns (c, K-1-c)): 16 loads per
+// row pair at K = 32 instead of ~48, every register index static, the next row pair's loads in flight under the current
+// pair's arithmetic.  Same operations in the same order on the same values: bit-identical to the scalar-width form, which
+// still serves float64 frames, other window sizes and every wave that holds a window crossing the frame's border.
+typedef float zk_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int QV>
+struct zk_pair_rows {
+  zk_f4u L0[QV], R0[QV], L1[QV], R1[QV];  // rows r and K-1-r: L*[j] = columns 4j .. 4j+3, R*[j] = columns K-4-4j .. K-1-4j
+};
+
+template <int NMAX, typename T, int QV>
 __global__ __launch_bounds__(256, (NMAX == 12 ? ZK_POINTS_W12 : 1)) void zk_points_sep_kernel(
     const T* __restrict__ img, const int32_t* __restrict__ pts, double* __restrict__ out,
     const zk_sep_row* __restrict__ rows, const double* __restrict__ xq, const double* __restrict__ tmat,
@@ -63,13 +78,53 @@ __global__ __launch_bounds__(256, (NMAX == 12 ? ZK_POINTS_W12 : 1)) void zk_poin
   const ZK_CONST int32_t* rtab = zk_const((const int32_t*)rows);
   const ZK_CONST double* px = zk_const(xq);
   const int Q = (K + 1) / 2;
-  for (int ri = 0; ri < n_tab_rows; ++ri) {
-    const int r = rtab[2 * ri], cmin = rtab[2 * ri + 1];
+  bool wide = false;
+  if constexpr (QV > 0 && sizeof(T) == 4) {
+    const bool inside = x0 >= 0 && y0 >= 0 && x0 + K <= W && y0 + K <= H;
+    wide = __all(inside) != 0;  // wave-uniform: one window across the border sends its whole wave down the scalar-width path
+  }
+  if constexpr (QV > 0 && sizeof(T) == 4) {
+    if (wide) {
+      const float* __restrict__ base = (const float*)img + (long long)y0 * W + x0;
+      auto load_pair = [&](zk_pair_rows<QV>& w, int r) __attribute__((always_inline)) {
+        const float* pa = base + (long long)r * W;
+        const float* pb = base + (long long)(K - 1 - r) * W;
+#pragma unroll
+        for (int j = 0; j < QV; ++j) {
+          w.L0[j] = *(const zk_f4u*)(pa + 4 * j);
+          w.R0[j] = *(const zk_f4u*)(pa + K - 4 - 4 * j);
+          w.L1[j] = *(const zk_f4u*)(pb + 4 * j);
+          w.R1[j] = *(const zk_f4u*)(pb + K - 4 - 4 * j);
+        }
+      };
+      auto compute = [&](const zk_pair_rows<QV>& w, int r, int cmin) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 4 * QV; ++c)
+          if (c >= cmin && c < Q)  // wave-uniform
+            acc.pixel((double)w.L0[c / 4][c % 4], (double)w.R0[c / 4][3 - c % 4], (double)w.L1[c / 4][c % 4],
+                      (double)w.R1[c / 4][3 - c % 4], px + c * ZK_SEP_ROW);
+        acc.row_end(px + r * ZK_SEP_ROW);
+      };
+      zk_pair_rows<QV> wa, wb;
+      if (n_tab_rows > 0) load_pair(wa, rtab[0]);
+      for (int ri = 0; ri < n_tab_rows; ri += 2) {
+        if (ri + 1 < n_tab_rows) load_pair(wb, rtab[2 * (ri + 1)]);
+        compute(wa, rtab[2 * ri], rtab[2 * ri + 1]);
+        if (ri + 1 >= n_tab_rows) break;
+        if (ri + 2 < n_tab_rows) load_pair(wa, rtab[2 * (ri + 2)]);
+        compute(wb, rtab[2 * (ri + 1)], rtab[2 * (ri + 1) + 1]);
+      }
+    }
+  }
+  if (!wide) {
+    for (int ri = 0; ri < n_tab_rows; ++ri) {
+      const int r = rtab[2 * ri], cmin = rtab[2 * ri + 1];
 #pragma unroll 2
-    for (int c = cmin; c < Q; ++c)
-      acc.pixel(px_at(r, c), px_at(r, K - 1 - c), px_at(K - 1 - r, c), px_at(K - 1 - r, K - 1 - c),
-                px + c * ZK_SEP_ROW);
-    acc.row_end(px + r * ZK_SEP_ROW);
+      for (int c = cmin; c < Q; ++c)
+        acc.pixel(px_at(r, c), px_at(r, K - 1 - c), px_at(K - 1 - r, c), px_at(K - 1 - r, K - 1 - c),
+                  px + c * ZK_SEP_ROW);
+      acc.row_end(px + r * ZK_SEP_ROW);
+    }
   }
   const ZK_CONST int32_t* cmap = zk_const(colmap);
   double* __restrict__ dst = out + pc * n_poly;
@@ -87,9 +142,21 @@ int launch_one(zk_plan* p, const void* img, const int32_t* pts, int64_t H, int64
   if (blocks > 0x7fffffffLL) return zk_fail(ZK_E_BADARG, "too many points for one launch");
   int rc = zk_prof_begin(p, s);
   if (rc) return rc;
-  hipLaunchKernelGGL((zk_points_sep_kernel<NMAX, T>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)img, pts, out,
-                     t->d_rows, t->d_xq, t->d_T, t->d_colmap, t->n_rows, p->size, (int)H, (int)W, (long long)n_points,
-                     p->n_poly, perm);
+#define ZK_POINTS_LAUNCH(QV)                                                                                              \
+  hipLaunchKernelGGL((zk_points_sep_kernel<NMAX, T, QV>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)img, pts, out, \
+                     t->d_rows, t->d_xq, t->d_T, t->d_colmap, t->n_rows, p->size, (int)H, (int)W, (long long)n_points,      \
+                     p->n_poly, perm)
+  // whole-row 16-byte loads: float32 frames, windows of 8 .. 64 px (ZK_POINTS_NO_WIDE=1 in the environment: A/B, tests)
+  const int K = p->size;
+  const bool wide_ok = sizeof(T) == 4 && K >= 8 && K <= 64 && !getenv("ZK_POINTS_NO_WIDE");
+  if constexpr (sizeof(T) == 4) {
+    if (wide_ok && K <= 32) ZK_POINTS_LAUNCH(4);
+    else if (wide_ok) ZK_POINTS_LAUNCH(8);
+    else ZK_POINTS_LAUNCH(0);
+  } else {
+    ZK_POINTS_LAUNCH(0);
+  }
+#undef ZK_POINTS_LAUNCH
   ZK_HIP(hipGetLastError());
   return zk_prof_end(p, s);
 }

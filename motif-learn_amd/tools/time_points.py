@@ -13,9 +13,13 @@ n_max = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 z = ZPs(n_max, 32); plan = z._device_plan()
 img = torch.from_numpy(honeycomb_frame(2048, seed=1)).cuda()
 rng = np.random.default_rng(0)
-for n_pts, kind, bucket in [(1 << 20, "random", True), (1 << 20, "random", False), (1 << 20, "sorted", True), (1 << 20, "sorted", False),
-                            (100000, "random", True), (100000, "random", False)]:
+for n_pts, kind, bucket, wide in [(1 << 20, "random", True, True), (1 << 20, "random", True, False), (1 << 20, "random", False, True),
+                                  (1 << 20, "random", False, False), (1 << 20, "sorted", True, True), (1 << 20, "sorted", False, False),
+                                  (100000, "random", True, True), (100000, "random", False, False)]:
     os.environ.pop("ZK_POINTS_NO_BUCKET", None)
+    os.environ.pop("ZK_POINTS_NO_WIDE", None)
+    if not wide:
+        os.environ["ZK_POINTS_NO_WIDE"] = "1"
     if not bucket:
         os.environ["ZK_POINTS_NO_BUCKET"] = "1"
     pts = rng.integers(16, 2048 - 16, size=(n_pts, 2)).astype(np.int32)
@@ -32,7 +36,7 @@ for n_pts, kind, bucket in [(1 << 20, "random", True), (1 << 20, "random", False
     torch.cuda.synchronize()
     k, ms = plan.profile_read(); plan.profile(False)
     per_call = ms * (k // 5 if k >= 5 else 1) / k      # the bucketing kernels are not profiled launches: HIP events around the moment kernel only
-    print(f"{n_pts:8d} {kind:6s} points, {'bucketed' if bucket else 'caller order'}: moment kernel {ms / k:7.3f} ms  {n_pts / (ms / k) / 1e3:8.1f} M points/s", flush=True)
+    print(f"{n_pts:8d} {kind:6s} points, {'bucketed' if bucket else 'caller order'}, {'16-B row loads' if wide else '4-B loads'}: moment kernel {ms / k:7.3f} ms  {n_pts / (ms / k) / 1e3:8.1f} M points/s", flush=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     for _ in range(5):

@@ -196,20 +196,23 @@ def test_key_points_in_bucket_order_are_bit_identical(native, zo, n_max, size, n
     z = _zps(n_max, size)
     plan = z._device_plan()
     d_img, d_pts = torch.from_numpy(frame).cuda(), torch.from_numpy(pts).cuda()
-    out = [torch.full((n_points, len(z.n)), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+    out = [torch.full((n_points, len(z.n)), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3)]
     from ctypes import c_void_p
-    for k, env in enumerate((None, "1")):
-        if env:
-            monkeypatch.setenv("ZK_POINTS_NO_BUCKET", env)
-        else:
-            monkeypatch.delenv("ZK_POINTS_NO_BUCKET", raising=False)
+    # default (bucket order, whole window rows as 16-byte loads) | caller's order | caller's order, 4-byte loads (round 1's kernel)
+    for k, env in enumerate(({}, {"ZK_POINTS_NO_BUCKET": "1"}, {"ZK_POINTS_NO_BUCKET": "1", "ZK_POINTS_NO_WIDE": "1"})):
+        for name in ("ZK_POINTS_NO_BUCKET", "ZK_POINTS_NO_WIDE"):
+            monkeypatch.delenv(name, raising=False)
+        for name, val in env.items():
+            monkeypatch.setenv(name, val)
         native.check(plan._lib.zk_transform_points_dev(plan._h, c_void_p(d_img.data_ptr()), native.ZK_F32, H, W, c_void_p(d_pts.data_ptr()),
                                                        n_points, c_void_p(out[k].data_ptr()), None), "zk_transform_points_dev")
         torch.cuda.synchronize()
-    monkeypatch.delenv("ZK_POINTS_NO_BUCKET", raising=False)
-    a, b = out[0].cpu().numpy(), out[1].cpu().numpy()
+    for name in ("ZK_POINTS_NO_BUCKET", "ZK_POINTS_NO_WIDE"):
+        monkeypatch.delenv(name, raising=False)
+    a, b, c = (o.cpu().numpy() for o in out)
     assert not np.isnan(a).any()
     np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
     pick = rng.choice(n_points, 200, replace=False)
     s1, s2 = size // 2, size - size // 2
     padded = np.pad(frame, size + 20)
