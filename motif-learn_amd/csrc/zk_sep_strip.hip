@@ -461,7 +461,9 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
 // form reads three 64-bit VGPR operands where the scalar form reads two (the VGPR-operand v_fmac_f64 runs at 0.8 of the
 // SGPR-operand one, tools/micro_dpp64.hip), the sweep carries a second branch per block, and VALU-busy stays at 0.73.
 // Requesting the y rows and the next record by hand at the row's start (they would ride on the sweep) needs 33 more live
-// SGPRs: 584 bytes of scratch.  Kept as an opt-in (ZK_STRIP_V3=1 in the environment, parity-tested) and as the record of
+// SGPRs: 584 bytes of scratch; as ordinary loads placed before the sweep the compiler keeps them there without a spill, and the
+// wave's life does not move (102.5 k clocks: the SIMD's other wave already covers those waits).  On a box that does not
+// throttle (both kernels at 2.38 GHz) the round-3 kernel is 4 % ahead: 0.688 against 0.715 ms.  Kept as an opt-in (ZK_STRIP_V3=1 in the environment, parity-tested) and as the record of
 // what bounds the round-3 kernel; ZK_PATH_AUTO stays on zk_frame_strip2_kernel.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef ZK_STRIP3
