@@ -463,7 +463,11 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
 // Requesting the y rows and the next record by hand at the row's start (they would ride on the sweep) needs 33 more live
 // SGPRs: 584 bytes of scratch; as ordinary loads placed before the sweep the compiler keeps them there without a spill, and the
 // wave's life does not move (102.5 k clocks: the SIMD's other wave already covers those waits).  On a box that does not
-// throttle (both kernels at 2.38 GHz) the round-3 kernel is 4 % ahead: 0.688 against 0.715 ms.  Kept as an opt-in (ZK_STRIP_V3=1 in the environment, parity-tested) and as the record of
+// throttle (both kernels at 2.38 GHz) the round-3 kernel is 4 % ahead: 0.688 against 0.715 ms.
+// Also built in round 4 and dropped: FOUR outputs per lane at one wave per SIMD (a frame row swept once for four outputs: ~2.9 k
+// operations per output instead of ~4.3 k).  Four accumulator sets are 360 registers, and only the 256 architectural VGPRs can be
+// VALU operands on gfx950 (the other 256 are AccVGPRs): the compiler parks half of the moments in AGPRs behind
+// v_accvgpr_read / _write and spills 968 bytes.  Two outputs per lane is what n_max 8 allows.  Kept as an opt-in (ZK_STRIP_V3=1 in the environment, parity-tested) and as the record of
 // what bounds the round-3 kernel; ZK_PATH_AUTO stays on zk_frame_strip2_kernel.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef ZK_STRIP3
