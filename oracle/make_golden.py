@@ -65,6 +65,17 @@ def structured(g, ZPs, get_patches, HoneyComb):
         g[f"st_Zf_{tag}"] = Zf[:, ri][:, :, ci]
         g[f"st_Zf_sum_{tag}"] = Zf.sum(axis=(1, 2))
         g[f"st_Zf_max_{tag}"] = np.abs(Zf).max()
+    # ---- configs[4]'s tail on a structured crop: the reference's rot_maps / |to_complex| / mirror_map (_zmoments.py:300-316, 420-493)
+    # of its own dense moments at n_max 10, 32-px windows -- what the fused device kernel replaces end to end
+    z10 = ZPs(10, 32)
+    crop = np.ascontiguousarray(lattice[100:100 + 46, 30:30 + 58])                   # (46, 58) float32
+    g["st_maps_frame_10_32"] = crop
+    zm = z10.transform(crop.astype(np.float64))
+    ri, ci = sample_index(46, 3), sample_index(58, 4)
+    g["st_maps_rot_10_32"] = zm.rot_maps([2, 3, 4, 6])[:, ri][:, :, ci]
+    g["st_maps_abs_10_32"] = np.abs(zm.to_complex().data)[:, ri][:, :, ci]
+    g["st_maps_mirror_10_32"] = zm.mirror_map()[ri][:, ci]
+    g["st_maps_rot_pnone_unsel012_10_32"] = zm.rot_maps([3, 5], p=None, m_unselect=(0, 1, 2))[:, ri][:, :, ci]
     # ---- configs[0]: the reference's own test image (datasets/_zps_test_data.py:62-65 -- HoneyCombLattice(size=512, l=12),
     # seeded here), 32-px patches, n_max 8: batch path on a strided grid of windows, dense path on the whole frame
     frame = HoneyComb(size=512, l=12, seed=0).to_image()

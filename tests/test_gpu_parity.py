@@ -962,3 +962,25 @@ def test_config0_frame_against_reference(native, golden):
     assert np.abs(d32[:, ri][:, :, ri] - golden["c0_Zf_f32_sample"]).max() <= 1e-6 * mx
     np.testing.assert_array_equal(z.transform(frame).valid_mask[ri][:, ri],
                                   np.pad(np.ones((512 - 31, 512 - 31), bool), ((15, 16), (15, 16)))[ri][:, ri])
+
+
+def test_fused_symmetry_maps_against_reference_on_a_structured_crop(native, golden):
+    """configs[4]'s parameters (n_max 10, 32-px windows): the fused frame -> maps kernel against the REFERENCE's own tail
+    (zmoments.rot_maps / to_complex / mirror_map of its dense moments, _zmoments.py:300-316, 420-493) on a honeycomb crop --
+    float64-cast in the reference, float32 and float64 in, here; strided positions incl. the zero-padded borders."""
+    z = _zps(10, 32)
+    crop = golden["st_maps_frame_10_32"]
+    ri, ci = _sample_index(46, 3), _sample_index(58, 4)
+    pick = lambda a: a[..., ri, :][..., ci]
+    for img in (crop, crop.astype(np.float64)):
+        maps = z.symmetry_maps(img)
+        np.testing.assert_allclose(pick(maps["rot_maps"]), golden["st_maps_rot_10_32"], rtol=1e-8, atol=1e-11)
+        rel_close(pick(maps["abs"]), golden["st_maps_abs_10_32"], rtol=1e-8)
+        np.testing.assert_allclose(pick(maps["mirror_map"]), golden["st_maps_mirror_10_32"], rtol=1e-8, atol=1e-11)
+        got = z.symmetry_maps(img, n_folds=[3, 5], p=None, m_unselect=(0, 1, 2), mirror=False, abs_moments=False)
+        np.testing.assert_allclose(pick(got["rot_maps"]), golden["st_maps_rot_pnone_unsel012_10_32"], rtol=1e-8,
+                                   atol=1e-12 * np.abs(golden["st_maps_rot_pnone_unsel012_10_32"]).max())
+        # the host container on the device moments: the same reference numbers
+        zm = z.transform(img)
+        np.testing.assert_allclose(pick(zm.rot_maps([2, 3, 4, 6])), golden["st_maps_rot_10_32"], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(pick(zm.mirror_map()), golden["st_maps_mirror_10_32"], rtol=1e-8, atol=1e-11)

@@ -184,3 +184,18 @@ def test_config0_frame_goldens_pin_the_oracle(golden):
     dense_at = got[:, grid[:-1] + 16][:, :, grid[:-1] + 16].reshape(45, -1).T
     batch_at = golden["c0_Z_grid_8_32"].reshape(31, 31, 45)[:-1, :-1].reshape(-1, 45)
     rel_close(dense_at, batch_at, rtol=1e-9)
+
+
+def test_symmetry_tail_goldens_on_a_structured_crop(golden):
+    """configs[4]'s parameters (n_max 10, 32-px): the reference's rot_maps / |to_complex| / mirror_map of its own dense moments of a
+    honeycomb crop, strided positions incl. the zero-padded borders -- the oracle's tail on the oracle's moments restates them."""
+    n, m, b = zo.zernike_basis(10, 32)
+    crop = golden["st_maps_frame_10_32"].astype(np.float64)
+    mom = zo.moments_frame_direct(crop, zo.convolution_basis(b, n))
+    ri, ci = sample_index(46, 3), sample_index(58, 4)
+    pick = lambda a: a[..., ri, :][..., ci]
+    np.testing.assert_allclose(pick(zo.rot_maps(mom, n, m, [2, 3, 4, 6])), golden["st_maps_rot_10_32"], rtol=1e-9, atol=1e-12)
+    rel_close(pick(np.abs(zo.to_complex(mom, n, m)[0])), golden["st_maps_abs_10_32"], rtol=1e-9)
+    np.testing.assert_allclose(pick(zo.mirror_map(mom, n, m)), golden["st_maps_mirror_10_32"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(pick(zo.rot_maps(mom, n, m, [3, 5], p=None, m_unselect=(0, 1, 2))),
+                               golden["st_maps_rot_pnone_unsel012_10_32"], rtol=1e-9, atol=1e-14)
