@@ -611,15 +611,24 @@ def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4, cpu_sample=
         whole = gather_labels(labels, comm)
         s_gather = worst(time.perf_counter() - t0)
         # one Lloyd pass on its own (the synchronous C-ABI call: centre table up, kernel, fixed-order reduction, k x (D+1) sums back)
+        import statistics
+
+        def timed_calls(call, warm=10, reps=12):
+            """Kernel time of a synchronous C-ABI pass (HIP events inside the library): `warm` untimed calls, then `reps` timed
+            ones; median, minimum, maximum (median of >= 10 after warm-up) and the wall clock per call."""
+            for _ in range(warm):
+                call()
+            ms, t0 = [], time.perf_counter()
+            for _ in range(reps):
+                call()
+                ms.append(rows.last_kernel_ms())
+            wall = (time.perf_counter() - t0) / reps
+            return {"median": worst(statistics.median(ms)), "min": min(ms), "max": max(ms), "timed_calls": reps, "warm_calls": warm}, worst(wall)
+
         centers0 = np.zeros((k, n_poly))
-        rows.lloyd(centers0, True)
         rows.profile(True)
-        t0, kernel_ms = time.perf_counter(), 0.0
-        for _ in range(5):
-            rows.lloyd(centers0, True)
-            kernel_ms += rows.last_kernel_ms() / 5
-        s_pass = worst((time.perf_counter() - t0) / 5)
-        kernel_ms = worst(kernel_ms)
+        lloyd_t, s_pass = timed_calls(lambda: rows.lloyd(centers0, True))
+        kernel_ms = lloyd_t["median"]
         # the two passes of a Gaussian-mixture EM iteration (gmm_lbs), k = 6 full covariances, on the same resident block: kernels
         # on the matrix cores; local passes only (no collective), every rank its own block
         kg = 6
@@ -628,14 +637,9 @@ def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4, cpu_sample=
         means_g = rng.standard_normal((kg, n_poly)) * 0.01
         log_det = np.log(np.einsum("kii->ki", prec)).sum(axis=1)
         log_w = np.log(np.full(kg, 1.0 / kg))
-        rows.estep(prec, means_g, log_det, log_w)
-        e_ms = m_ms = 0.0
-        for _ in range(3):
-            rows.estep(prec, means_g, log_det, log_w)
-            e_ms += rows.last_kernel_ms() / 3
-            rows.moments(0, np.zeros(n_poly), count=kg)
-            m_ms += rows.last_kernel_ms() / 3
-        e_ms, m_ms = worst(e_ms), worst(m_ms)
+        e_t, _ = timed_calls(lambda: rows.estep(prec, means_g, log_det, log_w))
+        m_t, _ = timed_calls(lambda: rows.moments(0, np.zeros(n_poly), count=kg))
+        e_ms, m_ms = e_t["median"], m_t["median"]
         rows.profile(False)
     finally:
         rows.close()
@@ -645,15 +649,19 @@ def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4, cpu_sample=
     if n_knn >= 1024:
         from mtflearn_amd.manifold import _knn_affinities
         with DeviceRows(mine[:n_knn].cpu().numpy()) as sub:
-            _knn_affinities(sub, 10, 1, 10)
-            t0 = time.perf_counter()
-            _knn_affinities(sub, 10, 1, 10)
-            s_knn = worst(time.perf_counter() - t0)
+            for _ in range(3):
+                _knn_affinities(sub, 10, 1, 10)
+            knn_s = []
+            for _ in range(10):
+                t0 = time.perf_counter()
+                _knn_affinities(sub, 10, 1, 10)
+                knn_s.append(time.perf_counter() - t0)
+            s_knn = worst(sorted(knn_s)[len(knn_s) // 2])
         steps = 12 if n_poly <= 48 else (n_poly + 15) // 16 * 4
         knn = {"workload": f"zk_rows_knn_correlation: 10 nearest neighbours (correlation distance) + affinities of {n_knn} x {n_poly} rows, "
                            "N^2 scalar products on the matrix cores with the top-k kept in the result lanes; wall clock of the C-ABI call "
                            "(kernels + three result copies to the host)",
-               "ms": s_knn * 1e3,
+               "ms": s_knn * 1e3, "ms_min": min(knn_s) * 1e3, "ms_max": max(knn_s) * 1e3, "timed_calls": len(knn_s), "warm_calls": 3,
                "roofline": {"bound": "mfma-f64", "achieved": 2.0 * n_knn * n_knn * 4 * steps / s_knn / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                             "frac": 2.0 * n_knn * n_knn * 4 * steps / s_knn / 1e12 / 78.6}}
     sizes = np.bincount(whole, minlength=k).astype(np.int64)
@@ -676,7 +684,7 @@ def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4, cpu_sample=
                         + (f"one block per rank: the ranks exchange {k} x {n_poly + 1} sums per pass and gather 4-byte labels, "
                            "never the moments" if world > 1 else "adopted where the batch kernel wrote it"),
             "k": k, "lloyd_iterations": n_iter, "s_fit": s_fit, "s_label_gather": s_gather,
-            "lloyd_pass": {"ms_per_call": s_pass * 1e3, "kernel_ms": kernel_ms, "bytes_per_rank": 8 * n_poly * n_local + 4 * n_local,
+            "lloyd_pass": {"ms_per_call": s_pass * 1e3, "kernel_ms": kernel_ms, "kernel_ms_spread": lloyd_t, "bytes_per_rank": 8 * n_poly * n_local + 4 * n_local,
                            "roofline": {"bound": "hbm", "achieved": (8 * n_poly + 4) * n_local / (kernel_ms * 1e-3) / 1e9,
                                         "peak": 8000.0, "unit": "GB/s",
                                         "frac": (8 * n_poly + 4) * n_local / (kernel_ms * 1e-3) / 1e9 / 8000.0}},
@@ -690,7 +698,7 @@ def clustering_section(comm, world, dev, mine, n_local, n_poly, k=4, cpu_sample=
         m_flop = kg * (nb * (nb + 1) // 2) * 16 * 2048.0 / 64 * n_local
         out["mixture_em"] = {"workload": f"one EM iteration of gmm_lbs (k = {kg}, full covariances) on the rank's ({n_local}, {n_poly}) block: "
                                          "E step (estep_mfma_kernel) and weighted second moments of all components (wgram_mfma_kernel)",
-                             "e_step_kernel_ms": e_ms, "m_step_kernel_ms": m_ms,
+                             "e_step_kernel_ms": e_ms, "m_step_kernel_ms": m_ms, "e_step_spread": e_t, "m_step_spread": m_t,
                              "e_step_roofline": {"bound": "mfma-f64", "achieved": e_flop / (e_ms * 1e-3) / 1e12, "peak": 78.6,
                                                  "unit": "TFLOP/s", "frac": e_flop / (e_ms * 1e-3) / 1e12 / 78.6},
                              "m_step_roofline": {"bound": "mfma-f64", "achieved": m_flop / (m_ms * 1e-3) / 1e12, "peak": 78.6,

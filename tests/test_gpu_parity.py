@@ -984,3 +984,21 @@ def test_fused_symmetry_maps_against_reference_on_a_structured_crop(native, gold
         zm = z.transform(img)
         np.testing.assert_allclose(pick(zm.rot_maps([2, 3, 4, 6])), golden["st_maps_rot_10_32"], rtol=1e-8, atol=1e-11)
         np.testing.assert_allclose(pick(zm.mirror_map()), golden["st_maps_mirror_10_32"], rtol=1e-8, atol=1e-11)
+
+
+def test_keypoints_moments_against_the_reference(native):
+    """mtflearn_amd.features.KeyPoints (the reference's class, features/_keypoint.py:53-92): border clearing + windows as the
+    reference cuts them, and `moments(zps)` -- the windows read from the resident frame on the GPU -- against the REFERENCE's
+    ZPs.transform of its own extracted patches (oracle/make_golden_keypoints.py), even and odd window sizes."""
+    import os
+    from conftest import ROOT
+    from mtflearn_amd.features import KeyPoints
+    with np.load(os.path.join(ROOT, "tests", "golden", "keypoints_golden.npz")) as f:
+        kg = {k: f[k] for k in f.files}
+    for size in (32, 33):
+        kp = KeyPoints(kg["pts"], kg["frame"], size)
+        z = _zps(8, size)
+        zm = kp.moments(z)
+        assert zm.data.shape == kg[f"Z_{size}"].shape and zm.patch_size == size
+        rel_close(zm.data, kg[f"Z_{size}"])
+        rel_close(z.transform(kp.extract_patches()).data, kg[f"Z_{size}"])          # the batch route: same numbers
