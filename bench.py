@@ -458,7 +458,9 @@ def worker(args):
                     counts = D.rccl_transport_summary(fh.read())
         except OSError:
             counts = {}
-        all_counts = [json.loads(b.decode()) for b in comm.allgather_host(json.dumps(counts).encode().ljust(256))]
+        blob = json.dumps(counts).encode()
+        blob = (blob if len(blob) <= 256 else b"{}").ljust(256)          # equal-sized payloads on every rank
+        all_counts = [json.loads(b.decode()) for b in comm.allgather_host(blob)]
         ranks_seen = int(comm.ranks_seen()) if backend == "rccl" else world
         link_GBps = rl.XGMI_LINKS * rl.XGMI_LINK_GBS
         received = (world - 1) * n_local * n_poly * 8 / (alone_ms * 1e-3) / 1e9
