@@ -18,7 +18,7 @@ import torch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--which", default="strip8,sep12,maps10,batch12,stream12")
+    ap.add_argument("--which", default="strip8,sep12,maps10,batch12,stream12,direct20,points8")
     args = ap.parse_args()
     from mtflearn_amd import ZPs, _native, distributed as D
     from mtflearn_amd.synthetic import honeycomb_frame
@@ -68,6 +68,32 @@ def main():
                     D.patch_moments_device(plan, p, out=out)
                 torch.cuda.synchronize()
         plan.set_path(_native.PATH_AUTO)
+    if "direct20" in which:                                             # what ZK_PATH_AUTO runs from n_max 17 (round 4): the plain sum on the matrix cores
+        z = zps(20, 40)
+        plan = z._device_plan()
+        f = torch.from_numpy(honeycomb_frame(2048, seed=0)).to(dev)
+        out = D.frame_moments_device(plan, f, row0=256, n_rows=512)
+        for _ in range(args.reps):
+            D.frame_moments_device(plan, f, row0=256, n_rows=512, out=out)
+        torch.cuda.synchronize()
+        del out
+        p = f.unfold(0, 40, 3).unfold(1, 40, 3).reshape(-1, 40, 40)[:1 << 18].contiguous()
+        o = D.patch_moments_device(plan, p)
+        for _ in range(args.reps):
+            D.patch_moments_device(plan, p, out=o)
+        torch.cuda.synchronize()
+        del o, p
+    if "points8" in which:                                              # moments at 2^20 random key points (bucketed, 16-byte row loads)
+        from ctypes import c_void_p
+        z = zps(8, 32)
+        plan = z._device_plan()
+        f = torch.from_numpy(honeycomb_frame(2048, seed=1)).to(dev)
+        pts = torch.from_numpy(np.random.default_rng(0).integers(16, 2032, size=(1 << 20, 2)).astype(np.int32)).to(dev)
+        o = torch.empty((1 << 20, 45), dtype=torch.float64, device=dev)
+        for _ in range(args.reps + 1):
+            _native.check(plan._lib.zk_transform_points_dev(plan._h, c_void_p(f.data_ptr()), 0, 2048, 2048, c_void_p(pts.data_ptr()), 1 << 20,
+                                                            c_void_p(o.data_ptr()), None), "points")
+        torch.cuda.synchronize()
     print("done")
 
 
