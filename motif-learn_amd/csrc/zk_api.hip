@@ -243,8 +243,13 @@ bool zk_plan_auto_direct(const zk_plan* p, int mode, int dtype) {
 // `n_units` = patches of the call (batch mode).
 static int resolve_path(const zk_plan* p, int mode, int dtype, int64_t n_units = 0) {
   if (p->path != ZK_PATH_AUTO) return path_available(p, mode, dtype, p->path) ? p->path : -1;
-  if (zk_plan_auto_direct(p, mode, dtype) && !getenv("ZK_NO_DIRECT"))
-    return mode == 1 || n_units >= 64 ? ZK_PATH_DIRECT : ZK_PATH_GENERIC;  // (less than a wave of patches: the per-lane sum)
+  if (!getenv("ZK_NO_DIRECT")) {
+    if (zk_plan_auto_direct(p, mode, dtype))
+      return mode == 1 || n_units >= 64 ? ZK_PATH_DIRECT : ZK_PATH_GENERIC;  // (less than a wave of patches: the per-lane sum)
+    // a full Zernike set of an order that AUTO serves with the plain sum, but outside the matrix-core kernels' shapes (dense windows
+    // whose staged tile exceeds the LDS: float64 above ~100 px, float32 above ~150): the per-lane plain sum -- slow, and exact
+    if (p->sep && zk_full_set_nmax(p) >= p->auto_direct_from) return ZK_PATH_GENERIC;
+  }
   if (mode == 0 && path_available(p, mode, dtype, ZK_PATH_STREAM) &&
       (zk_sep_stream_preferred(p, dtype, n_units) || !path_available(p, mode, dtype, ZK_PATH_SEPARABLE)))
     return ZK_PATH_STREAM;

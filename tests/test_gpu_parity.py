@@ -1002,3 +1002,19 @@ def test_keypoints_moments_against_the_reference(native):
         assert zm.data.shape == kg[f"Z_{size}"].shape and zm.patch_size == size
         rel_close(zm.data, kg[f"Z_{size}"])
         rel_close(z.transform(kp.extract_patches()).data, kg[f"Z_{size}"])          # the batch route: same numbers
+
+
+def test_auto_never_takes_the_polynomial_kernels_above_n_max_16(native, zo):
+    """A window too large for the matrix-core dense kernel's LDS tile (float64, 106 px: 155 KB) but not for the separable kernel's
+    (147 KB), at an order AUTO serves with the plain sum: the per-lane plain sum runs instead of the separable family -- slow, and
+    exact (the contract of INTEGRATION section 4)."""
+    z = _zps(18, 106)
+    plan = z._device_plan()
+    assert not plan.has_path(1, native.ZK_F64, native.PATH_DIRECT) and plan.has_path(1, native.ZK_F64, native.PATH_SEPARABLE)
+    assert plan.best_path(1, native.ZK_F64) == native.PATH_GENERIC
+    assert plan.best_path(0, native.ZK_F64, 1000) == native.PATH_DIRECT and plan.best_path(0, native.ZK_F64, 10) == native.PATH_GENERIC
+    rng = np.random.default_rng(3)
+    img = rng.random((110, 120))
+    ref = zo.moments_frame_direct(img, _dense_basis(zo, z), rows=[0, 53, 109], cols=[0, 64, 119])
+    got = z.transform(img).data[:, [0, 53, 109]][:, :, [0, 64, 119]]
+    rel_close(got, ref, atol_scale=1e-11)
