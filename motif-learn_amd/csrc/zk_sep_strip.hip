@@ -467,7 +467,14 @@ __global__ __launch_bounds__(256, 2) void zk_frame_strip2_kernel(
 // Also built in round 4 and dropped: FOUR outputs per lane at one wave per SIMD (a frame row swept once for four outputs: ~2.9 k
 // operations per output instead of ~4.3 k).  Four accumulator sets are 360 registers, and only the 256 architectural VGPRs can be
 // VALU operands on gfx950 (the other 256 are AccVGPRs): the compiler parks half of the moments in AGPRs behind
-// v_accvgpr_read / _write and spills 968 bytes.  Two outputs per lane is what n_max 8 allows.  Kept as an opt-in (ZK_STRIP_V3=1 in the environment, parity-tested) and as the record of
+// v_accvgpr_read / _write and spills 968 bytes.  Two outputs per lane is what n_max 8 allows in ONE pass.
+// THREE outputs per lane in two parity passes (the form of n_max 9-12: a pass carries the 25 / 20 moments of one x parity, so
+// three sets fit; ~3.2 k operations per output; x table in VGPR lanes, LDS requests three blocks ahead) was built too, gives the
+// same bits, and runs 1.4x SLOWER (205 k clocks per 3 outputs against 97 k per 2): every pass reads the pixel pair of a block
+// again, a pass's block is 5-6 f64 operations, and eight waves of a CU then ask the LDS for 64 clocks of reads per 48 clocks
+// of arithmetic -- the sweeps become LDS-bound.  (With scalar table rows, one block ahead, the same form ran 1.7x slower.)
+// The round-3 kernel is balanced at three limits at once: per round of its eight waves 88 clocks of FP64 issue, ~91 clocks
+// of scalar-operand delivery (512 B at ~5.6 B per clock) and 64 clocks of LDS reads.  Kept as an opt-in (ZK_STRIP_V3=1 in the environment, parity-tested) and as the record of
 // what bounds the round-3 kernel; ZK_PATH_AUTO stays on zk_frame_strip2_kernel.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef ZK_STRIP3

@@ -53,9 +53,11 @@ def main():
                 D.frame_moments_device(plan, f, out=out)
             torch.cuda.synchronize()
             t = buf.cpu().numpy().reshape(-1, 10).astype(np.int64)
+            t = t[t[:, 0] > 0]                                  # (kernels with taller workgroups leave the rest of the buffer untouched)
+            buf.zero_()
             rt, ck = t[:, 0:4], t[:, 4:8]
             ghz = (ck[:, 3] - ck[:, 0]) / ((rt[:, 3] - rt[:, 0]) * 10.0)
-            print(f"  k = {k:4d}: {np.median(ghz):.3f} GHz   {(rt[:, 3].max() - rt[:, 0].min()) / 100.0:8.1f} us   wave life {np.mean(ck[:, 3] - ck[:, 0]):.0f} clocks", flush=True)
+            print(f"  k = {k:4d}: {np.median(ghz):.3f} GHz   {(rt[:, 3].max() - rt[:, 0].min()) / 100.0:8.1f} us   wave life {np.mean(ck[:, 3] - ck[:, 0]):.0f} clocks   ({len(t)} waves)", flush=True)
         lib.zk_debug_strip_trace(ctypes.c_void_p(0))
         return
     for _ in range(a.reps):                       # warm: clocks up, the traced launch is the last of a back-to-back run
@@ -72,6 +74,7 @@ def main():
     plan.profile(False)
     lib.zk_debug_strip_trace(ctypes.c_void_p(0))
     t = buf.cpu().numpy().reshape(-1, 10).astype(np.int64)
+    t = t[t[:, 0] > 0]
     rt, ck, hw, xcc = t[:, 0:4], t[:, 4:8], t[:, 8], t[:, 9] & 0xf
     t0, t1 = rt[:, 0].min(), rt[:, 3].max()
     dur_us = (t1 - t0) / 100.0
