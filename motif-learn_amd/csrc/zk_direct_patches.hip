@@ -12,26 +12,29 @@
 // the scalar cache: 0.5 M patches/s at (72, 36)); a DMA-staged version with the table in SGPRs still waited ~40 clocks per FMA
 // for scalars out of a 5-MB table.  So: v_mfma_f64_16x16x4_f64, both operands from vector memory.
 //
-//   wave = 64 patches (4 blocks of 16) x CH = 96 functions (6 blocks of 16): 24 accumulator blocks of 4 doubles per lane;
-//   patches move as in zk_sep_patches.hip: a unit = four 64-B runs (16 float32 / 8 float64 pixels each, pieces of the disk
-//   rows) of all 64 patches = 16 KiB, moved by 16 global_load_lds_dwordx4 (each: one run of 16 patches), the granule a lane
-//   fetches rotated by its patch index -- the per-lane 4-byte read of "pixel s of patch p" below is then bank-conflict-free;
+//   wave = 64 patches (4 blocks of 16) x CH <= 96 functions (FB <= 6 blocks of 16): up to 24 accumulator blocks of 4 doubles
+//   per lane.  The set's ceil(NP / 16) blocks are dealt to the fewest chunks of at most 6 as evenly as they go (325 functions =
+//   21 blocks = 6 + 5 + 5 + 5: 336 columns of arithmetic where four chunks of 96 do 384), the wider chunks first;
+//   patches move as in zk_sep_patches.hip: a run = 64 B (16 float32 / 8 float64 pixels, a piece of a disk row) of all 64
+//   patches = 4 KiB, moved by 4 global_load_lds_dwordx4 (each: the run of 16 patches), the granule a lane fetches rotated by
+//   its patch index; a wave's slab holds four runs (a unit) and a run's piece is re-armed, three runs ahead, as soon as its
+//   steps have read it;
 //   k dimension = pixels, 4 per MFMA: A[i][k] = pixel (4 step + k) of patch 16 pb + i (LDS, converted to float64),
-//   B[k][j] = table row of that pixel, function 16 fb + j (global memory: [unit][pixel slot][CH] float64, the caller's values
+//   B[k][j] = table row of that pixel, function 16 fb + j ([unit][pixel slot][CH] float64 in global memory, the caller's values
 //   / area, zero rows where a run overlaps its neighbour or leaves the disk -- every disk pixel is owned by exactly one slot,
-//   checked at plan creation; steps whose four rows are all zero are skipped);
-//   the functions are done CH at a time: one launch per chunk over the same patches (the patches come from L2 / Infinity Cache
-//   after the first chunk); results go straight into the (N, n_poly) rows (16 consecutive functions per 128-B segment).
+//   checked at plan creation; steps whose four rows are all zero are skipped).  The rows reach the waves through LDS: a
+//   workgroup's waves walk the runs together and share one copy (below);
+//   the functions are done CH at a time: one launch per chunk over the same patches; results go straight into the
+//   (N, n_poly) rows (16 consecutive functions per 128-B segment).
 #include <math.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "zk_fold.h"
 
-#ifndef ZK_DIRECT_CH
-#define ZK_DIRECT_CH 96  // functions per launch: 24 accumulator blocks = 192 registers, two waves per SIMD
-#endif
+#define ZK_DIRECT_FB_MAX 6  // function blocks of 16 per chunk: 24 accumulator blocks = 192 registers, two waves per SIMD
 
 struct zk_direct_unit {
   int32_t run_off[4];  // byte offsets of the unit's four runs inside a patch
@@ -43,10 +46,14 @@ struct zk_direct_unit {
 
 struct zk_direct_tables {
   int n_chunks = 0;
+  int fb_hi = ZK_DIRECT_FB_MAX;  // chunks 0 .. n_hi - 1 hold fb_hi blocks of 16 functions, the other n_chunks - n_hi hold fb_hi - 1
+  int n_hi = 0;
+  int chunk_fb(int c) const { return c < n_hi ? fb_hi : fb_hi - 1; }
+  int chunk_col0(int c) const { return 16 * (c < n_hi ? c * fb_hi : n_hi * fb_hi + (c - n_hi) * (fb_hi - 1)); }
   struct per_type {
     int n_units = 0;
     zk_direct_unit* d_units = nullptr;
-    double* d_tab = nullptr;  // [n_chunks][n_units][4 runs x UP slots][CH]
+    double* d_tab = nullptr;  // chunk after chunk: [n_units][4 runs x UP slots][CH of the chunk]
   } t[2];                     // [0] float32 (UP = 16 pixels per run), [1] float64 (UP = 8)
   // dense mode: the disk rows in pieces of 4 consecutive pixels (a piece = one MFMA step)
   int n_steps = 0;
@@ -54,13 +61,11 @@ struct zk_direct_tables {
   bool flipped = false;           // the dense table holds (-1)^n V(K-1-r, K-1-c): what the reference's convolution multiplies
   int32_t* d_step_off = nullptr;  // [n_steps] bits 0..23: tile element offset of the piece's first pixel (window row r:
                                   // r * tile_pitch + c); bits 24..27: which of its 4 slots stand for a disk pixel
-  double* d_ftab = nullptr;       // [n_chunks][n_steps][4][CH]
+  double* d_ftab = nullptr;       // chunk after chunk: [n_steps][4][CH of the chunk]
 };
 
 namespace {
 
-constexpr int CH = ZK_DIRECT_CH;
-constexpr int FB = CH / 16;  // function blocks
 
 #define ZK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define ZK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -73,68 +78,90 @@ int upload(T** dst, const std::vector<T>& src) {
   return 0;
 }
 
-// one chunk of CH functions (columns col0 .. col0 + n_live - 1 of the result) for all patches
-template <typename TIN, bool ROLL>
-__global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __restrict__ in, double* __restrict__ out,
-                                                                 const zk_direct_unit* __restrict__ units,
-                                                                 const double* __restrict__ tab, int n_units, int col0, int n_live,
-                                                                 int n_poly, long long n_patches, int patch_bytes) {
+// Four pixels (one per block of 16 patches: 1 KiB apart) of run image RHO (the images are 4 KiB apart; addr = the pixel's place
+// in image 0), read by instructions the compiler does not know to be LDS reads: it makes every LDS read it knows of wait for
+// ALL LDS DMA in flight (s_waitcnt vmcnt(0): it cannot tell the pieces of the slab apart), which would put the wait for a
+// piece's re-arm DMA right behind its issue.
+struct zk_px4_f32 {
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  v2 lo, hi;
+  template <int RHO>
+  __device__ __forceinline__ void issue_at(unsigned addr) {
+    asm volatile("ds_read2st64_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read2st64_b32 %1, %2 offset0:%5 offset1:%6"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(addr), "n"(16 * RHO), "n"(16 * RHO + 4), "n"(16 * RHO + 8), "n"(16 * RHO + 12));
+  }
+  __device__ __forceinline__ void wait() { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)); }
+  __device__ __forceinline__ double get(int pb) const { return (double)(pb < 2 ? lo[pb & 1] : hi[pb & 1]); }
+};
+struct zk_px4_f64 {
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  v2 lo, hi;
+  template <int RHO>
+  __device__ __forceinline__ void issue_at(unsigned addr) {
+    asm volatile("ds_read2st64_b64 %0, %2 offset0:%3 offset1:%4\n\tds_read2st64_b64 %1, %2 offset0:%5 offset1:%6"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(addr), "n"(8 * RHO), "n"(8 * RHO + 2), "n"(8 * RHO + 4), "n"(8 * RHO + 6));
+  }
+  __device__ __forceinline__ void wait() { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)); }
+  __device__ __forceinline__ double get(int pb) const { return pb < 2 ? lo[pb & 1] : hi[pb & 1]; }
+};
+template <typename TIN> struct zk_px4;
+template <> struct zk_px4<float> { typedef zk_px4_f32 type; };
+template <> struct zk_px4<double> { typedef zk_px4_f64 type; };
+__device__ __forceinline__ unsigned zk_lds_offset(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
+
+// ---- the batch kernel ------------------------------------------------------------------------------------------------------
+// Round 3's form had every wave fetch a step's table rows from L2 for itself, right before the step's MFMAs.  Those loads count
+// on vmcnt behind the slab's re-arm DMA (in order), so every re-arm's HBM latency sat in front of a row load: 0.60-0.71 of the
+// FP64 peak where the arithmetic alone, re-arm and row loads compiled out, ran at 0.75-0.86 (profiles/r04_direct_batch.txt).
+// Here a workgroup's WAVES waves walk the runs together: the rows of run r + 1 arrive by DMA (each wave moves a share) while
+// run r is computed, one barrier per run hands them over, and a step's operands are LDS reads issued a step ahead -- vmcnt
+// counts DMA only, so "this run has landed" is an exact count.
+//   table piece of a run in LDS: [step pair][function block][step of the pair][k][16 functions] float64 = 512 B per (step,
+//   block), which lane (k, j) = lane 16 k + j reads at 8 lane: one conflict-free ds_read_b64 per MFMA B operand;
+//   a 1-KiB DMA instruction = one function block of a step pair; two pieces (run r, run r + 1) behind the WAVES 16-KiB slabs:
+//   8 waves (152 KiB, two per SIMD) from 512 patches per CU on, 4 waves (88 KiB) for smaller batches.
+template <int I, int N, typename F>
+__device__ __forceinline__ void zk_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    zk_static_for<I + 1, N>(f);
+  }
+}
+
+template <typename TIN, int FB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void zk_patch_direct_kernel(const TIN* __restrict__ in, double* __restrict__ out,
+                                                                          const zk_direct_unit* __restrict__ units,
+                                                                          const double* __restrict__ tab, int n_units, int col0,
+                                                                          int n_live, int n_poly, long long n_patches, int patch_bytes) {
   typedef double v4d __attribute__((ext_vector_type(4)));
-  constexpr int PXG = 16 / sizeof(TIN);  // pixels per 16-B granule: 4 (float32) or 2 (float64)
+  constexpr int CH = 16 * FB;
+  constexpr int PXG = 16 / sizeof(TIN);  // steps per run: 4 (float32) or 2 (float64)
   constexpr int UP = 4 * PXG;            // pixels per run
-  static_assert(UP == 4 * PXG, "a run = PXG steps of 4 slots");
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // one 16-KiB slab per wave
+  constexpr int SP = PXG / 2;            // step pairs per run
+  constexpr int PIECE = SP * FB * 1024;  // bytes of a run's table rows
+  constexpr int N_INSTR = SP * FB;       // DMA instructions that move a piece
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const TIN* const ws = (const TIN*)(lds + wave * 4096);
-  const long long patch0 = ((long long)blockIdx.x * 4 + wave) * 64;
-  if (patch0 >= n_patches) return;  // (no barrier in this kernel: a wave only reads LDS bytes it DMA'd itself)
+  char* const ring = (char*)lds + WAVES * 16384;
+  const long long patch0 = ((long long)blockIdx.x * WAVES + wave) * 64;
   const long long left = n_patches - patch0;
-  const int nv = left < 64 ? (int)left : 64;
+  // a wave past the end of the batch keeps the workgroup's barriers and its share of the table DMA: it reads patch 0, stores nothing
+  const int nv = left <= 0 ? 0 : left < 64 ? (int)left : 64;
 
-  // ---- DMA addressing (as zk_sep_patches.hip, 64-B runs): lane -> (patch-in-group a, slot b) ---------------------------
   const int a = lane >> 2, b = lane & 3;
   const int g0 = (b - (a >> 2)) & 3;  // source granule: rotated by the patch index
-  const char* const wbase = (const char*)in + patch0 * patch_bytes;
+  const char* const wbase = (const char*)in + (nv > 0 ? patch0 : 0) * patch_bytes;
   int poff[4];
 #pragma unroll
   for (int pg = 0; pg < 4; ++pg) {
     int pi = pg * 16 + a;
-    pi = pi < nv ? pi : nv - 1;  // tail wave: re-read the last live patch
+    pi = pi < nv ? pi : (nv > 0 ? nv - 1 : 0);
     poff[pg] = pi * patch_bytes + g0 * 16;
   }
   const ZK_CONST int32_t* utab = zk_const((const int32_t*)units);  // 8 ints per unit
-  auto issue = [&](int u) {
-#pragma unroll
-    for (int rho = 0; rho < 4; ++rho) {
-      const int ro = utab[8 * u + rho];
-#pragma unroll
-      for (int pg = 0; pg < 4; ++pg)
-        __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(wbase + (poff[pg] + ro)), ZK_LDS_PTR(lds + wave * 4096 + (rho * 4 + pg) * 256),
-                                         16, 0, 0);
-    }
-  };
-
-  // ---- MFMA operand addressing: lane = (i = lane & 15, k = lane >> 4) -----------------------------------------------------
-  // pixel slot s = 4 step + k of run rho = step / PXG... a run holds UP = 4 PXG slots = PXG steps; inside the run, slot
-  // x = 4 (step % PXG) + k lies in granule x / PXG at element x % PXG; patch p = 16 pb + i sits at 64 B * p of the run image
-  // with its granules rotated by p >> 2
-  const int li = lane & 15, kr = lane >> 4;
-  int pbase[4];  // element index of (patch 16 pb + i, granule 0) inside a run image
-#pragma unroll
-  for (int pb = 0; pb < 4; ++pb) pbase[pb] = (16 * pb + li) * UP;
-  const int prot = li >> 2;  // (16 pb + i) >> 2 = 4 pb + (i >> 2): the same rotation mod 4 for every pb
-  v4d acc[4][FB];
-#pragma unroll
-  for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-    for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = v4d{0.0, 0.0, 0.0, 0.0};
-  const double* __restrict__ tlane = tab + (size_t)kr * CH + li;  // this lane's column of a step's four table rows
-
-  // Rolling re-arm (round 4): a run's 4-KiB piece of the slab is free as soon as its PXG steps have read it, so the next unit's
-  // run goes into it at once and has the other three runs' arithmetic (12 steps x 24 MFMAs) to land -- the DMA latency that the
-  // whole-slab form exposed once per unit is hidden.  Vector-memory operations complete in order: at the start of a run the only
-  // younger ones are the four DMA instructions issued at the end of the previous run, so vmcnt(4) says "this run has landed".
   auto issue_run = [&](int u, int rho) {
     const int ro = utab[8 * u + rho];
 #pragma unroll
@@ -142,74 +169,101 @@ __global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __re
       __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(wbase + (poff[pg] + ro)), ZK_LDS_PTR(lds + wave * 4096 + (rho * 4 + pg) * 256), 16,
                                        0, 0);
   };
-  (void)issue;
+  // table DMA: lane -> (step of the pair h, k, granule g of the block's 128 B)
+  const int t_off = ((((lane >> 5) * 4 + ((lane >> 3) & 3)) * CH) + 2 * (lane & 7)) * 8;
+  const char* const tbytes = (const char*)tab;
+  auto issue_table = [&](int r) {
 #pragma unroll
-  for (int rho = 0; rho < 4; ++rho) issue_run(0, rho);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (!ROLL) {  // the round-3 form: the whole slab re-armed after the unit's last step (ZK_DIRECT_NO_ROLL=1 / 0 forces either)
-    for (int u = 0; u < n_units; ++u) {
-      const int steps = utab[8 * u + 4];
-      const unsigned own_lo = (unsigned)utab[8 * u + 5], own_hi = (unsigned)utab[8 * u + 6];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const double* __restrict__ tu = tlane + (size_t)u * (4 * UP) * CH;
-#pragma unroll 2
-      for (int st = 0; st < 4 * PXG; ++st) {
-        if (!((steps >> st) & 1)) continue;
-        const int rho = st / PXG;
-        const int x = 4 * (st % PXG) + kr;
-        const int gsl = ((x / PXG + prot) & 3) * PXG + x % PXG;
-        double av[4], bv[FB];
-        const bool mine = (((st < 8 ? own_lo : own_hi) >> (4 * (st & 7) + kr)) & 1u) != 0;
-#pragma unroll
-        for (int pb = 0; pb < 4; ++pb) {
-          const double v = (double)ws[rho * 64 * UP + pbase[pb] + gsl];
-          av[pb] = mine ? v : 0.0;
-        }
-        const double* __restrict__ tr = tu + (size_t)st * 4 * CH;
-#pragma unroll
-        for (int fb = 0; fb < FB; ++fb) bv[fb] = tr[16 * fb];
-#pragma unroll
-        for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-          for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb], bv[fb], acc[pb][fb], 0, 0, 0);
+    for (int i0 = 0; i0 < N_INSTR; i0 += WAVES) {
+      const int i = i0 + wave;
+      if (i < N_INSTR) {
+        const int sp = i / FB, fb = i - sp * FB;
+        __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(tbytes + ((size_t)r * UP * CH + sp * 8 * CH + 16 * fb) * 8 + t_off),
+                                         ZK_LDS_PTR(ring + (r & 1) * PIECE + i * 1024), 16, 0, 0);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (u + 1 < n_units) issue(u + 1);
     }
-  } else
+  };
+
+  const int li = lane & 15, kr = lane >> 4;
+  const int prot = li >> 2;
+  unsigned px_addr[PXG];  // LDS byte address of (patch li, this lane's slot of step sr) in run image 0
+#pragma unroll
+  for (int sr = 0; sr < PXG; ++sr) {
+    const int x = 4 * sr + kr;
+    const int gsl = ((x / PXG + prot) & 3) * PXG + x % PXG;
+    px_addr[sr] = zk_lds_offset(lds + wave * 4096) + (unsigned)((li * UP + gsl) * sizeof(TIN));
+  }
+  const unsigned b_addr = zk_lds_offset(ring) + 8u * lane;
+  v4d acc[4][FB];
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  // as if the tops of runs -3, -2, -1 had been passed: a run's top issues the table of the next run, then the patches' run 3 ahead
+  const int n_runs = 4 * n_units;
+  issue_run(0, 0);
+  issue_run(0, 1);
+  issue_table(0);
+  issue_run(0, 2);
   for (int u = 0; u < n_units; ++u) {
     const int steps = utab[8 * u + 4];
     const unsigned own_lo = (unsigned)utab[8 * u + 5], own_hi = (unsigned)utab[8 * u + 6];
-    const double* __restrict__ tu = tlane + (size_t)u * (4 * UP) * CH;
+    zk_static_for<0, 4>([&](auto rho_c) {
+      constexpr int RHO = decltype(rho_c)::value;
+      const int r = 4 * u + RHO;
+      // everything but the youngest four DMA instructions (the patches' run r + 2, if there is one) has landed: this wave's share
+      // of run r's rows and its patches' run r
+      if (r + 2 < n_runs)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave's share has, and every wave is done with run r - 1 (its rows' piece is free)
+      if (r + 1 < n_runs) issue_table(r + 1);
+      if (r + 3 < n_runs) issue_run(RHO == 0 ? u : u + 1, (RHO + 3) & 3);
+      // a step's operands are read (into a second set of registers) before the step ahead of it multiplies
+      typename zk_px4<TIN>::type px[2];
+      double bv[2][FB];
+      auto read_step = [&](auto sr_c) {
+        constexpr int SR = decltype(sr_c)::value;
+        px[SR & 1].template issue_at<RHO>(px_addr[SR]);
+        zk_static_for<0, FB>([&](auto fb_c) {
+          constexpr int F = decltype(fb_c)::value;
+          double row;  // (an asm operand may not name a variable of the enclosing lambda)
+          asm volatile("ds_read_b64 %0, %1 offset:%2"
+                       : "=v"(row)
+                       : "v"(b_addr), "n"((RHO & 1) * PIECE + ((SR / 2) * FB + F) * 1024 + (SR & 1) * 512));
+          bv[SR & 1][F] = row;
+        });
+      };
+      read_step(std::integral_constant<int, 0>{});
+      zk_static_for<0, PXG>([&](auto sr_c) {
+        constexpr int SR = decltype(sr_c)::value;
+        constexpr int ST = RHO * PXG + SR;
+        constexpr int B = SR & 1;
+        px[B].wait();  // (LDS reads return in order: this step's are older than any of the next step's)
+        if constexpr (FB == 6)
+          asm volatile("" : "+v"(bv[B][0]), "+v"(bv[B][1]), "+v"(bv[B][2]), "+v"(bv[B][3]), "+v"(bv[B][4]), "+v"(bv[B][5]));
+        else if constexpr (FB == 5)
+          asm volatile("" : "+v"(bv[B][0]), "+v"(bv[B][1]), "+v"(bv[B][2]), "+v"(bv[B][3]), "+v"(bv[B][4]));
+        else if constexpr (FB == 4)
+          asm volatile("" : "+v"(bv[B][0]), "+v"(bv[B][1]), "+v"(bv[B][2]), "+v"(bv[B][3]));
+        else
+          asm volatile("" : "+v"(bv[B][0]), "+v"(bv[B][1]), "+v"(bv[B][2]));
+        if constexpr (SR + 1 < PXG) read_step(std::integral_constant<int, SR + 1>{});
+        if ((steps >> ST) & 1) {  // wave-uniform, and the same in every wave: a dead step has four zero rows
+          const bool mine = (((ST < 8 ? own_lo : own_hi) >> (4 * (ST & 7) + kr)) & 1u) != 0;
+          double av[4];
 #pragma unroll
-    for (int rho = 0; rho < 4; ++rho) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // run rho of unit u has landed (issued a unit ago)
+          for (int pb = 0; pb < 4; ++pb) av[pb] = mine ? px[B].get(pb) : 0.0;
 #pragma unroll
-      for (int sr = 0; sr < PXG; ++sr) {
-        const int st = rho * PXG + sr;
-        if (!((steps >> st) & 1)) continue;  // wave-uniform: four zero rows
-        const int x = 4 * sr + kr;                                     // slot inside the run
-        const int gsl = ((x / PXG + prot) & 3) * PXG + x % PXG;        // its element inside the patch's (rotated) 64 B
-        double av[4], bv[FB];
-        const bool mine = (((st < 8 ? own_lo : own_hi) >> (4 * (st & 7) + kr)) & 1u) != 0;
+          for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb) {
-          const double v = (double)ws[rho * 64 * UP + pbase[pb] + gsl];
-          av[pb] = mine ? v : 0.0;
+            for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb], bv[B][fb], acc[pb][fb], 0, 0, 0);
         }
-        const double* __restrict__ tr = tu + (size_t)st * 4 * CH;
-#pragma unroll
-        for (int fb = 0; fb < FB; ++fb) bv[fb] = tr[16 * fb];
-#pragma unroll
-        for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-          for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb], bv[fb], acc[pb][fb], 0, 0, 0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this run's piece of the slab is no longer read
-      if (u + 1 < n_units) issue_run(u + 1, rho);
-    }
+      });
+    });
   }
-  // D layout: lane holds rows (patch-in-block) kr + 4 q, column (function-in-block) li
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
@@ -224,35 +278,53 @@ __global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __re
     }
 }
 
+template <typename TIN, int FB>
+int launch_chunk(zk_plan* p, int waves, int64_t n, const TIN* src, double* out, const zk_direct_tables::per_type& t, const double* tab,
+                 int col0, int n_live, int patch_bytes, hipStream_t s) {
+  constexpr int PIECE = (int)(16 / sizeof(TIN) / 2) * FB * 1024;
+  const int lds = waves * 16384 + 2 * PIECE;
+  const unsigned blocks = (unsigned)((n + 64 * waves - 1) / (64 * waves));
+  auto kern = waves == 8 ? zk_patch_direct_kernel<TIN, FB, 8> : zk_patch_direct_kernel<TIN, FB, 4>;
+  ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), lds, s, src, out, t.d_units, tab, t.n_units, col0, n_live, p->n_poly,
+                     (long long)n, patch_bytes);
+  ZK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename TIN>
 int launch_t(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
   const zk_direct_tables* d = p->direct;
   const zk_direct_tables::per_type& t = d->t[sizeof(TIN) == 4 ? 0 : 1];
   constexpr int UP = 64 / (int)sizeof(TIN);
   const size_t patch_elems = (size_t)p->size * p->size;
-  const size_t tab_chunk = (size_t)t.n_units * 4 * UP * CH;
   // (every chunk's launch streams the patches again: 8 x 20.7 KB per patch at (72, 36) against 5.5 MFLOP -- a quarter of the
   //  arithmetic's time at the HBM rate, and it overlaps)
   const int64_t round_max = (int64_t)1 << 22;
   for (int64_t first = 0; first < n_patches; first += round_max) {
     const int64_t n = std::min<int64_t>(n_patches - first, round_max);
     const TIN* src = (const TIN*)in + first * patch_elems;
-    const unsigned blocks = (unsigned)((n + 255) / 256);
+    // 8 waves per workgroup (two per SIMD) once that fills every CU, 4 below (one workgroup per CU either way): ZK_DIRECT_WAVES
+    int waves = n >= (int64_t)512 * p->n_cu ? 8 : 4;
+    if (const char* f = getenv("ZK_DIRECT_WAVES")) waves = atoi(f) == 8 ? 8 : 4;
+    const double* tab = t.d_tab;
     for (int c = 0; c < d->n_chunks; ++c) {
-      const int n_live = std::min(CH, p->n_poly - c * CH);
+      const int fb = d->chunk_fb(c), col0 = d->chunk_col0(c);
+      const int n_live = std::min(16 * fb, p->n_poly - col0);
       int rc = zk_prof_begin(p, s);
       if (rc) return rc;
-      // whole-slab re-arm when every SIMD holds two waves (the other wave hides the DMA wait: 0.64-0.84 of the FP64 peak,
-      // 2 % ahead of the rolling form); rolling re-arm for batches that leave CUs half empty (+7 %): profiles/r04_direct_batch.txt
-      const char* force = getenv("ZK_DIRECT_NO_ROLL");
-      if (force ? *force == '1' : blocks >= 2u * (unsigned)p->n_cu)
-        hipLaunchKernelGGL((zk_patch_direct_kernel<TIN, false>), dim3(blocks), dim3(256), 65536, s, src, out + first * p->n_poly, t.d_units,
-                           t.d_tab + c * tab_chunk, t.n_units, c * CH, n_live, p->n_poly, (long long)n, (int)(patch_elems * sizeof(TIN)));
-      else
-        hipLaunchKernelGGL((zk_patch_direct_kernel<TIN, true>), dim3(blocks), dim3(256), 65536, s, src, out + first * p->n_poly, t.d_units,
-                           t.d_tab + c * tab_chunk, t.n_units, c * CH, n_live, p->n_poly, (long long)n, (int)(patch_elems * sizeof(TIN)));
-      ZK_HIP(hipGetLastError());
+      double* o = out + first * p->n_poly;
+      const int pb = (int)(patch_elems * sizeof(TIN));
+      switch (fb) {
+        case 6: rc = launch_chunk<TIN, 6>(p, waves, n, src, o, t, tab, col0, n_live, pb, s); break;
+        case 5: rc = launch_chunk<TIN, 5>(p, waves, n, src, o, t, tab, col0, n_live, pb, s); break;
+        case 4: rc = launch_chunk<TIN, 4>(p, waves, n, src, o, t, tab, col0, n_live, pb, s); break;
+        case 3: rc = launch_chunk<TIN, 3>(p, waves, n, src, o, t, tab, col0, n_live, pb, s); break;
+        default: return zk_fail(ZK_E_BADARG, "internal: direct chunk width");
+      }
+      if (rc) return rc;
       if ((rc = zk_prof_end(p, s))) return rc;
+      tab += (size_t)t.n_units * 4 * UP * 16 * fb;
     }
   }
   return 0;
@@ -261,12 +333,59 @@ int launch_t(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStre
 // Dense mode of the same sum: 8 output rows x 64 columns per workgroup, the zero-padded tile staged once in LDS (in the
 // image's own element type) and walked once per chunk; wave = one output row = 64 positions (4 blocks of 16) x CH functions.
 // A step = 4 consecutive pixels of a disk row: A[i][k] = tile[window origin of position 16 pb + i + piece offset + k].
-template <typename TIN>
+template <typename TIN, int F>
+__device__ __forceinline__ void zk_frame_direct_chunk(const TIN* __restrict__ mine, const ZK_CONST int32_t* soff, const double* __restrict__ tl,
+                                                      int n_steps, int kr, double* __restrict__ dst0, int n_live, int li, bool row_live,
+                                                      int cols_left, long long plane) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  if constexpr (F >= 1) {
+    constexpr int CH = 16 * F;
+    v4d acc[4][F];
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+      for (int fb = 0; fb < F; ++fb) acc[pb][fb] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int st = 0; st < n_steps; ++st) {
+      const int so = soff[st];
+      const TIN* __restrict__ px = mine + (so & 0xffffff);
+      const bool own = ((so >> (24 + kr)) & 1) != 0;
+      double av[4], bv[F];
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) {
+        const double v = (double)px[16 * pb];
+        av[pb] = own ? v : 0.0;
+      }
+      const double* __restrict__ tr = tl + (size_t)st * 4 * CH;
+#pragma unroll
+      for (int fb = 0; fb < F; ++fb) bv[fb] = tr[16 * fb];
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+        for (int fb = 0; fb < F; ++fb) acc[pb][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb], bv[fb], acc[pb][fb], 0, 0, 0);
+    }
+    if (row_live) {
+#pragma unroll
+      for (int fb = 0; fb < F; ++fb) {
+        const bool col_live = 16 * fb + li < n_live;
+        double* __restrict__ dst = dst0 + (long long)(16 * fb) * plane;
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ok = 16 * pb + kr + 4 * q;
+            if (col_live && ok < cols_left) dst[ok] = acc[pb][fb][q];
+          }
+      }
+    }
+  }
+}
+
+// FB = blocks of 16 functions in the first n_hi chunks; the other n_chunks - n_hi hold FB - 1
+template <typename TIN, int FB>
 __global__ __launch_bounds__(512) void zk_frame_direct_kernel(const TIN* __restrict__ img, double* __restrict__ out,
                                                                const int32_t* __restrict__ step_off, const double* __restrict__ tab,
-                                                               int n_steps, int n_chunks, int n_poly, int K, int H, int W, int row0,
-                                                               int n_rows, int tile_pitch, long long plane) {
-  typedef double v4d __attribute__((ext_vector_type(4)));
+                                                               int n_steps, int n_chunks, int n_hi, int n_poly, int K, int H, int W,
+                                                               int row0, int n_rows, int tile_pitch, long long plane) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   TIN* const tile = (TIN*)lds;
   const int lane = threadIdx.x & 63;
@@ -296,54 +415,28 @@ __global__ __launch_bounds__(512) void zk_frame_direct_kernel(const TIN* __restr
   const ZK_CONST int32_t* soff = zk_const(step_off);
   const int oi = i0 + wave;
   const bool row_live = oi < row0 + n_rows;
-  for (int ch = 0; ch < n_chunks; ++ch) {
-    v4d acc[4][FB];
-#pragma unroll
-    for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-      for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = v4d{0.0, 0.0, 0.0, 0.0};
-    const double* __restrict__ tl = tab + ((size_t)ch * n_steps * 4 + kr) * CH + li;
-    for (int st = 0; st < n_steps; ++st) {
-      const int so = soff[st];
-      const TIN* __restrict__ px = mine + (so & 0xffffff);
-      const bool own = ((so >> (24 + kr)) & 1) != 0;
-      double av[4], bv[FB];
-#pragma unroll
-      for (int pb = 0; pb < 4; ++pb) {
-        const double v = (double)px[16 * pb];
-        av[pb] = own ? v : 0.0;
-      }
-      const double* __restrict__ tr = tl + (size_t)st * 4 * CH;
-#pragma unroll
-      for (int fb = 0; fb < FB; ++fb) bv[fb] = tr[16 * fb];
-#pragma unroll
-      for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-        for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pb], bv[fb], acc[pb][fb], 0, 0, 0);
-    }
-    if (row_live) {
-      const int n_live = n_poly - ch * CH < CH ? n_poly - ch * CH : CH;
-#pragma unroll
-      for (int fb = 0; fb < FB; ++fb) {
-        const bool col_live = 16 * fb + li < n_live;
-        double* __restrict__ dst = out + (long long)(ch * CH + 16 * fb + li) * plane + (long long)(oi - row0) * W + k0;
-#pragma unroll
-        for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int ok = 16 * pb + kr + 4 * q;
-            if (col_live && k0 + ok < W) dst[ok] = acc[pb][fb][q];
-          }
-      }
-    }
+  double* __restrict__ const orow = out + (long long)(oi - row0) * W + k0;
+  const double* __restrict__ tl = tab + (size_t)kr * (16 * FB) + li;
+  int col0 = 0;
+  for (int ch = 0; ch < n_hi; ++ch) {
+    zk_frame_direct_chunk<TIN, FB>(mine, soff, tl, n_steps, kr, orow + (long long)(col0 + li) * plane, n_poly - col0, li, row_live, W - k0, plane);
+    tl += (size_t)n_steps * 4 * (16 * FB);
+    col0 += 16 * FB;
+  }
+  tl -= kr * 16;  // the narrower chunks' rows are 16 (FB - 1) wide
+  for (int ch = n_hi; ch < n_chunks; ++ch) {
+    zk_frame_direct_chunk<TIN, FB - 1>(mine, soff, tl, n_steps, kr, orow + (long long)(col0 + li) * plane, n_poly - col0, li, row_live, W - k0,
+                                       plane);
+    tl += (size_t)n_steps * 4 * (16 * (FB - 1));
+    col0 += 16 * (FB - 1);
   }
 }
 
-template <typename TIN>
-int launch_frame_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out, hipStream_t s) {
+template <typename TIN, int FB>
+int launch_frame_fb(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out, hipStream_t s) {
   const zk_direct_tables* d = p->direct;
   const size_t lds = (size_t)(p->size + 7) * d->tile_pitch * sizeof(TIN);
-  auto kern = zk_frame_direct_kernel<TIN>;
+  auto kern = zk_frame_direct_kernel<TIN, FB>;
   if (lds > 64 * 1024)
     ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long long plane = zk_out_plane(p, n_rows, W);
@@ -352,10 +445,20 @@ int launch_frame_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row
     int rc = zk_prof_begin(p, s);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const TIN*)in, out + off, d->d_step_off, d->d_ftab, d->n_steps, d->n_chunks,
-                       p->n_poly, p->size, (int)H, (int)W, (int)r0, (int)nr, d->tile_pitch, plane);
+                       d->n_hi, p->n_poly, p->size, (int)H, (int)W, (int)r0, (int)nr, d->tile_pitch, plane);
     ZK_HIP(hipGetLastError());
     return zk_prof_end(p, s);
   });
+}
+
+template <typename TIN>
+int launch_frame_t(zk_plan* p, const void* in, int64_t H, int64_t W, int64_t row0, int64_t n_rows, double* out, hipStream_t s) {
+  switch (p->direct->fb_hi) {
+    case 6: return launch_frame_fb<TIN, 6>(p, in, H, W, row0, n_rows, out, s);
+    case 5: return launch_frame_fb<TIN, 5>(p, in, H, W, row0, n_rows, out, s);
+    case 4: return launch_frame_fb<TIN, 4>(p, in, H, W, row0, n_rows, out, s);
+    default: return zk_fail(ZK_E_BADARG, "internal: direct chunk width");
+  }
 }
 
 }  // namespace
@@ -385,7 +488,17 @@ int zk_direct_build(zk_plan* p, const double* basis) {
       if (basis[(size_t)j * K * K + t] != 0.0) act[t] = 1;
   zk_direct_tables* d = new zk_direct_tables();
   p->direct = d;
-  d->n_chunks = (NP + CH - 1) / CH;
+  // chunks: the set's blocks of 16 functions dealt to the fewest chunks of at most 6, as evenly as they go (ZK_DIRECT_CH96=1:
+  // round 3's chunks of 96 whatever the set, for comparison)
+  {
+    const int blocks = (NP + 15) / 16;
+    d->n_chunks = (blocks + ZK_DIRECT_FB_MAX - 1) / ZK_DIRECT_FB_MAX;
+    d->fb_hi = (blocks + d->n_chunks - 1) / d->n_chunks;
+    d->n_hi = blocks % d->n_chunks ? blocks % d->n_chunks : d->n_chunks;
+    if (getenv("ZK_DIRECT_CH96")) d->fb_hi = ZK_DIRECT_FB_MAX, d->n_hi = d->n_chunks;
+  }
+  size_t cols = 0;  // columns of all chunks together
+  for (int c = 0; c < d->n_chunks; ++c) cols += 16 * d->chunk_fb(c);
   for (int dt = 0; dt < 2; ++dt) {
     const int es = dt == 0 ? 4 : 8, UP = 64 / es;
     // runs: the disk segment [lo, hi) of every row in pieces of UP pixels; the last piece of a row is moved back so that it
@@ -435,13 +548,16 @@ int zk_direct_build(zk_plan* p, const double* basis) {
     }
     zk_direct_tables::per_type& t = d->t[dt];
     t.n_units = n_units;
-    std::vector<double> tab((size_t)d->n_chunks * n_units * slots * CH, 0.0);
-    for (int c = 0; c < d->n_chunks; ++c)
+    std::vector<double> tab(owner.size() * cols + 4 * 16 * ZK_DIRECT_FB_MAX, 0.0);  // (+ one step: the kernels fetch rows one step ahead)
+    for (int c = 0; c < d->n_chunks; ++c) {
+      const int CH = 16 * d->chunk_fb(c), col0 = d->chunk_col0(c);
+      double* const chunk = &tab[owner.size() * col0];  // (the chunks before this one hold col0 columns of every slot)
       for (size_t k = 0; k < owner.size(); ++k) {
         if (owner[k] < 0) continue;
-        double* dst = &tab[((size_t)c * owner.size() + k) * CH];
-        for (int i = 0; i < CH && c * CH + i < NP; ++i) dst[i] = basis[(size_t)(c * CH + i) * K * K + owner[k]] * inv_area;
+        double* dst = chunk + k * CH;
+        for (int i = 0; i < CH && col0 + i < NP; ++i) dst[i] = basis[(size_t)(col0 + i) * K * K + owner[k]] * inv_area;
       }
+    }
     int rc = upload(&t.d_units, units);
     if (!rc) rc = upload(&t.d_tab, tab);
     if (rc) return rc;
@@ -486,13 +602,16 @@ int zk_direct_build(zk_plan* p, const double* basis) {
         return zk_fail(ZK_E_BADARG, "internal: direct dense pieces do not tile the disk");
       }
     d->n_steps = (int)soff.size();
-    std::vector<double> ftab((size_t)d->n_chunks * owner.size() * CH, 0.0);
-    for (int c = 0; c < d->n_chunks; ++c)
+    std::vector<double> ftab(owner.size() * cols + 4 * 16 * ZK_DIRECT_FB_MAX, 0.0);
+    for (int c = 0; c < d->n_chunks; ++c) {
+      const int CH = 16 * d->chunk_fb(c), col0 = d->chunk_col0(c);
+      double* const chunk = &ftab[owner.size() * col0];
       for (size_t k = 0; k < owner.size(); ++k) {
         if (owner[k] < 0) continue;
-        double* dst = &ftab[((size_t)c * owner.size() + k) * CH];
-        for (int i = 0; i < CH && c * CH + i < NP; ++i) dst[i] = value(c * CH + i, owner[k]) * inv_area;
+        double* dst = chunk + k * CH;
+        for (int i = 0; i < CH && col0 + i < NP; ++i) dst[i] = value(col0 + i, owner[k]) * inv_area;
       }
+    }
     int rc = upload(&d->d_step_off, soff);
     if (!rc) rc = upload(&d->d_ftab, ftab);
     if (rc) return rc;

@@ -46,7 +46,8 @@ def main():
         auto = [_native.PATH_NAMES[plan.best_path(0, _native.ZK_F32, 1 << 20)], _native.PATH_NAMES[plan.best_path(1, _native.ZK_F64)]]
         print(f"--- n_max {n_max} K {K} ({len(z.n)} moments)   ZK_PATH_AUTO: batch {auto[0]}, dense {auto[1]}")
         n_t = 1 << 18 if K <= 48 else 1 << 17
-        pt = frame.unfold(0, K, 5).unfold(1, K, 5).reshape(-1, K, K)[:n_t].contiguous()
+        pt = frame.unfold(0, K, 3).unfold(1, K, 3).reshape(-1, K, K)[:n_t].contiguous()
+        assert pt.shape[0] == n_t, pt.shape  # (a stride of 5 px leaves 161 604 windows of 40 px on a 2048^2 frame: fewer than 2^18)
         for path, name in _native.PATH_NAMES.items():
             line = f"  {name:10s}"
             if plan.has_path(0, _native.ZK_F32, path):
