@@ -56,6 +56,7 @@ def parse():
                     help="skip the north star's own size (it launches the same kernel as the timed loop: use this "
                          "flag under rocprofv3 --stats so that the average is the timed loop's)")
     ap.add_argument("--no-config2", action="store_true", help="skip configs[2] (4096^2, 64-px, n_max 12)")
+    ap.add_argument("--no-high-order", action="store_true", help="skip the matrix-core plain sum at (40 px, n_max 20)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the NumPy-in / NumPy-out measurement")
     ap.add_argument("--no-multi-frame", action="store_true", help="N>1: skip configs[3] (8 frames per rank)")
     ap.add_argument("--only-timed-loop", action="store_true", help="skip every side measurement (profiling runs)")
@@ -1022,6 +1023,41 @@ def single_gpu_sections(args, result, dev, plan, z, f_dev, frame):
             "fp64_flops_per_position": flops,
             "roofline": _fp64_roofline(4096 * 4096 * flops, 4096 * 4096 * rl.dense_bytes_per_position(12), ms, t["shader_clock_ghz"])}
         del od, f2, plan12, z12
+        torch.cuda.empty_cache()
+
+    # ---- the orders the reference's estimator returns for larger windows: the plain sum on the matrix cores ------
+    # (what ZK_PATH_AUTO runs from n_max 17: every disk pixel times the caller's own float64 basis value)
+    if not args.no_high_order:
+        z20 = ZPs(n_max=20, size=40)
+        plan20 = z20._device_plan()
+        fh = torch.from_numpy(honeycomb_frame(2048, seed=5)).to(dev)
+        n_t = 1 << 18
+        pt = fh.unfold(0, 40, 3).unfold(1, 40, 3).reshape(-1, 40, 40)[:n_t].contiguous()
+        assert pt.shape[0] == n_t
+        useful = rl.direct_flops_per_unit(z20.polynomials[0], 20)       # 2 x disk pixels x 231 functions
+        kernels = {"batch": _native.PATH_NAMES[plan20.best_path(0, _native.ZK_F32, n_t)], "dense": _native.PATH_NAMES[plan20.best_path(1, _native.ZK_F32)]}
+
+        def mfma_roofline(units, t):
+            tf = units * useful / (t.ms * 1e-3) / 1e12
+            r = {"bound": "mfma", "achieved": tf, "peak": rl.FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s (useful f64: 2 x disk pixels x functions)",
+                 "frac": tf / rl.FP64_VECTOR_PEAK_TF}
+            if t["shader_clock_ghz"]:
+                r["shader_clock_ghz"] = t["shader_clock_ghz"]
+                r["frac_at_clock"] = r["frac"] * 2.4 / t["shader_clock_ghz"]
+            return r
+
+        oh = torch.empty((n_t, len(z20.n)), dtype=torch.float64, device=dev)
+        t = _profiled(plan20, lambda: D.patch_moments_device(plan20, pt, out=oh))
+        sec = {"workload": f"n_max=20 on 40-px windows (231 moments): {n_t} float32 windows as a batch; a 512-row band of a 2048x2048 frame densely",
+               "kernels": kernels, "useful_fp64_flops_per_unit": useful,
+               "batch": {"kernel_ms": t.ms, "patches_per_s": n_t / (t.ms * 1e-3), **_spread(t), "roofline": mfma_roofline(n_t, t)}}
+        del oh, pt
+        band = 512
+        od = torch.empty((len(z20.n), band, 2048), dtype=torch.float64, device=dev)
+        t = _profiled(plan20, lambda: D.frame_moments_device(plan20, fh, row0=256, n_rows=band, out=od))
+        sec["dense"] = {"kernel_ms": t.ms, "positions_per_s": band * 2048 / (t.ms * 1e-3), **_spread(t), "roofline": mfma_roofline(band * 2048, t)}
+        result["high_order"] = sec
+        del od, fh, plan20, z20
         torch.cuda.empty_cache()
 
     # ---- configs[4]: full symmetry-map pipeline, 4096^2, n_max = 10, fused on device ---------------------------
