@@ -501,8 +501,8 @@ int zk_direct_build(zk_plan* p, const double* basis) {
   for (int c = 0; c < d->n_chunks; ++c) cols += 16 * d->chunk_fb(c);
   for (int dt = 0; dt < 2; ++dt) {
     const int es = dt == 0 ? 4 : 8, UP = 64 / es;
-    // runs: the disk segment [lo, hi) of every row in pieces of UP pixels; the last piece of a row is moved back so that it
-    // ends inside the row (it then overlaps its neighbour: the overlapped slots own nothing)
+    // runs: the disk segment [lo, hi) of every row in pieces of UP pixels; a piece at the patch's very end is moved back so that it
+    // ends inside the patch (it then overlaps its neighbour: the overlapped slots own nothing)
     std::vector<int> run_off;  // byte offset of each run
     std::vector<int> owner;    // [run][UP]: pixel index r * K + c the slot stands for, or -1
     std::vector<int> cover((size_t)K * K, 0);
@@ -514,7 +514,10 @@ int zk_direct_build(zk_plan* p, const double* basis) {
           hi = c + 1;
         }
       for (int c0 = lo; c0 < hi; c0 += UP) {
-        const int start = std::min(c0, K - UP);
+        // (a piece starts where the one before it ended, running on into the next row's bytes if it must -- its steps then stay
+        //  aligned with the row's first disk pixel: 306 instead of 318 steps at 40 px; only a piece that would leave the PATCH is
+        //  moved back to end with it)
+        const int start = r * K + c0 + UP <= K * K ? c0 : K - UP;
         run_off.push_back((r * K + start) * es);
         for (int x = 0; x < UP; ++x) {
           const int c = start + x;
