@@ -17,8 +17,8 @@
 //   21 blocks = 6 + 5 + 5 + 5: 336 columns of arithmetic where four chunks of 96 do 384), the wider chunks first;
 //   patches move as in zk_sep_patches.hip: a run = 64 B (16 float32 / 8 float64 pixels, a piece of a disk row) of all 64
 //   patches = 4 KiB, moved by 4 global_load_lds_dwordx4 (each: the run of 16 patches), the granule a lane fetches rotated by
-//   its patch index; a wave's slab holds four runs (a unit) and a run's piece is re-armed, three runs ahead, as soon as its
-//   steps have read it;
+//   its patch index; a wave's slab holds three runs and a run's image is re-armed, two runs ahead, as soon as its steps have
+//   read it;
 //   k dimension = pixels, 4 per MFMA: A[i][k] = pixel (4 step + k) of patch 16 pb + i (LDS, converted to float64),
 //   B[k][j] = table row of that pixel, function 16 fb + j ([unit][pixel slot][CH] float64 in global memory, the caller's values
 //   / area, zero rows where a run overlaps its neighbour or leaves the disk -- every disk pixel is owned by exactly one slot,
@@ -115,13 +115,13 @@ __device__ __forceinline__ unsigned zk_lds_offset(const void* p) { return (unsig
 // Round 3's form had every wave fetch a step's table rows from L2 for itself, right before the step's MFMAs.  Those loads count
 // on vmcnt behind the slab's re-arm DMA (in order), so every re-arm's HBM latency sat in front of a row load: 0.60-0.71 of the
 // FP64 peak where the arithmetic alone, re-arm and row loads compiled out, ran at 0.75-0.86 (profiles/r04_direct_batch.txt).
-// Here a workgroup's WAVES waves walk the runs together: the rows of run r + 1 arrive by DMA (each wave moves a share) while
-// run r is computed, one barrier per run hands them over, and a step's operands are LDS reads issued a step ahead -- vmcnt
-// counts DMA only, so "this run has landed" is an exact count.
+// Here a workgroup's four waves (one per SIMD; two workgroups per CU) walk the runs together: the rows of run r + 1 arrive by DMA
+// (each wave moves a share) while run r is computed, one barrier per run hands them over, and a step's operands are LDS reads
+// issued a step ahead -- vmcnt counts DMA only, so "this run has landed" is an exact count.
 //   table piece of a run in LDS: [step pair][function block][step of the pair][k][16 functions] float64 = 512 B per (step,
 //   block), which lane (k, j) = lane 16 k + j reads at 8 lane: one conflict-free ds_read_b64 per MFMA B operand;
-//   a 1-KiB DMA instruction = one function block of a step pair; two pieces (run r, run r + 1) behind the WAVES 16-KiB slabs:
-//   8 waves (152 KiB, two per SIMD) from 512 patches per CU on, 4 waves (88 KiB) for smaller batches.
+//   a 1-KiB DMA instruction = one function block of a step pair; two pieces (run r, run r + 1) behind the four 12-KiB slabs
+//   (three run images each: the run being read and the next two on their way): 72 KiB per workgroup at 96 functions.
 template <int I, int N, typename F>
 __device__ __forceinline__ void zk_static_for(F&& f) {
   if constexpr (I < N) {
@@ -130,8 +130,8 @@ __device__ __forceinline__ void zk_static_for(F&& f) {
   }
 }
 
-template <typename TIN, int FB, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void zk_patch_direct_kernel(const TIN* __restrict__ in, double* __restrict__ out,
+template <typename TIN, int FB>
+__global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __restrict__ in, double* __restrict__ out,
                                                                           const zk_direct_unit* __restrict__ units,
                                                                           const double* __restrict__ tab, int n_units, int col0,
                                                                           int n_live, int n_poly, long long n_patches, int patch_bytes) {
@@ -145,7 +145,8 @@ __global__ __launch_bounds__(64 * WAVES) void zk_patch_direct_kernel(const TIN* 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  char* const ring = (char*)lds + WAVES * 16384;
+  constexpr int WAVES = 4;
+  char* const ring = (char*)lds + WAVES * 12288;  // the waves' slabs (three 4-KiB run images each), then the two table pieces
   const long long patch0 = ((long long)blockIdx.x * WAVES + wave) * 64;
   const long long left = n_patches - patch0;
   // a wave past the end of the batch keeps the workgroup's barriers and its share of the table DMA: it reads patch 0, stores nothing
@@ -162,11 +163,11 @@ __global__ __launch_bounds__(64 * WAVES) void zk_patch_direct_kernel(const TIN* 
     poff[pg] = pi * patch_bytes + g0 * 16;
   }
   const ZK_CONST int32_t* utab = zk_const((const int32_t*)units);  // 8 ints per unit
-  auto issue_run = [&](int u, int rho) {
+  auto issue_run = [&](int u, int rho, int image) {  // run rho of unit u into run image `image` of the wave's slab
     const int ro = utab[8 * u + rho];
 #pragma unroll
     for (int pg = 0; pg < 4; ++pg)
-      __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(wbase + (poff[pg] + ro)), ZK_LDS_PTR(lds + wave * 4096 + (rho * 4 + pg) * 256), 16,
+      __builtin_amdgcn_global_load_lds(ZK_GLOBAL_PTR(wbase + (poff[pg] + ro)), ZK_LDS_PTR(lds + wave * 3072 + (image * 4 + pg) * 256), 16,
                                        0, 0);
   };
   // table DMA: lane -> (step of the pair h, k, granule g of the block's 128 B)
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64 * WAVES) void zk_patch_direct_kernel(const TIN* 
   for (int sr = 0; sr < PXG; ++sr) {
     const int x = 4 * sr + kr;
     const int gsl = ((x / PXG + prot) & 3) * PXG + x % PXG;
-    px_addr[sr] = zk_lds_offset(lds + wave * 4096) + (unsigned)((li * UP + gsl) * sizeof(TIN));
+    px_addr[sr] = zk_lds_offset(lds + wave * 3072) + (unsigned)((li * UP + gsl) * sizeof(TIN));
   }
   const unsigned b_addr = zk_lds_offset(ring) + 8u * lane;
   v4d acc[4][FB];
@@ -200,33 +201,36 @@ __global__ __launch_bounds__(64 * WAVES) void zk_patch_direct_kernel(const TIN* 
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) acc[pb][fb] = v4d{0.0, 0.0, 0.0, 0.0};
 
-  // as if the tops of runs -3, -2, -1 had been passed: a run's top issues the table of the next run, then the patches' run 3 ahead
+  // as if the tops of runs -2, -1 had been passed: a run's top issues the table of the next run, then the patches' run 2 ahead into
+  // the image that the run before it has just left (run r lives in image r mod 3)
   const int n_runs = 4 * n_units;
-  issue_run(0, 0);
-  issue_run(0, 1);
+  issue_run(0, 0, 0);
   issue_table(0);
-  issue_run(0, 2);
+  issue_run(0, 1, 1);
+  int image = 0;  // r mod 3
   for (int u = 0; u < n_units; ++u) {
     const int steps = utab[8 * u + 4];
     const unsigned own_lo = (unsigned)utab[8 * u + 5], own_hi = (unsigned)utab[8 * u + 6];
     zk_static_for<0, 4>([&](auto rho_c) {
       constexpr int RHO = decltype(rho_c)::value;
       const int r = 4 * u + RHO;
-      // everything but the youngest four DMA instructions (the patches' run r + 2, if there is one) has landed: this wave's share
+      // everything but the youngest four DMA instructions (the patches' run r + 1, if there is one) has landed: this wave's share
       // of run r's rows and its patches' run r
-      if (r + 2 < n_runs)
+      if (r + 1 < n_runs)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave's share has, and every wave is done with run r - 1 (its rows' piece is free)
       if (r + 1 < n_runs) issue_table(r + 1);
-      if (r + 3 < n_runs) issue_run(RHO == 0 ? u : u + 1, (RHO + 3) & 3);
+      if (r + 2 < n_runs) issue_run(RHO < 2 ? u : u + 1, (RHO + 2) & 3, image == 0 ? 2 : image - 1);
+      const unsigned image_at = 4096u * image;
+      image = image == 2 ? 0 : image + 1;
       // a step's operands are read (into a second set of registers) before the step ahead of it multiplies
       typename zk_px4<TIN>::type px[2];
       double bv[2][FB];
       auto read_step = [&](auto sr_c) {
         constexpr int SR = decltype(sr_c)::value;
-        px[SR & 1].template issue_at<RHO>(px_addr[SR]);
+        px[SR & 1].template issue_at<0>(px_addr[SR] + image_at);
         zk_static_for<0, FB>([&](auto fb_c) {
           constexpr int F = decltype(fb_c)::value;
           double row;  // (an asm operand may not name a variable of the enclosing lambda)
@@ -279,15 +283,14 @@ __global__ __launch_bounds__(64 * WAVES) void zk_patch_direct_kernel(const TIN* 
 }
 
 template <typename TIN, int FB>
-int launch_chunk(zk_plan* p, int waves, int64_t n, const TIN* src, double* out, const zk_direct_tables::per_type& t, const double* tab,
-                 int col0, int n_live, int patch_bytes, hipStream_t s) {
+int launch_chunk(zk_plan* p, int64_t n, const TIN* src, double* out, const zk_direct_tables::per_type& t, const double* tab, int col0,
+                 int n_live, int patch_bytes, hipStream_t s) {
   constexpr int PIECE = (int)(16 / sizeof(TIN) / 2) * FB * 1024;
-  const int lds = waves * 16384 + 2 * PIECE;
-  const unsigned blocks = (unsigned)((n + 64 * waves - 1) / (64 * waves));
-  auto kern = waves == 8 ? zk_patch_direct_kernel<TIN, FB, 8> : zk_patch_direct_kernel<TIN, FB, 4>;
+  const int lds = 4 * 12288 + 2 * PIECE;  // <= 72 KiB: two workgroups per CU
+  auto kern = zk_patch_direct_kernel<TIN, FB>;
   ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), lds, s, src, out, t.d_units, tab, t.n_units, col0, n_live, p->n_poly,
-                     (long long)n, patch_bytes);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, s, src, out, t.d_units, tab, t.n_units, col0, n_live,
+                     p->n_poly, (long long)n, patch_bytes);
   ZK_HIP(hipGetLastError());
   return 0;
 }
@@ -304,9 +307,6 @@ int launch_t(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStre
   for (int64_t first = 0; first < n_patches; first += round_max) {
     const int64_t n = std::min<int64_t>(n_patches - first, round_max);
     const TIN* src = (const TIN*)in + first * patch_elems;
-    // 8 waves per workgroup (two per SIMD) once that fills every CU, 4 below (one workgroup per CU either way): ZK_DIRECT_WAVES
-    int waves = n >= (int64_t)512 * p->n_cu ? 8 : 4;
-    if (const char* f = getenv("ZK_DIRECT_WAVES")) waves = atoi(f) == 8 ? 8 : 4;
     const double* tab = t.d_tab;
     for (int c = 0; c < d->n_chunks; ++c) {
       const int fb = d->chunk_fb(c), col0 = d->chunk_col0(c);
@@ -316,10 +316,10 @@ int launch_t(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStre
       double* o = out + first * p->n_poly;
       const int pb = (int)(patch_elems * sizeof(TIN));
       switch (fb) {
-        case 6: rc = launch_chunk<TIN, 6>(p, waves, n, src, o, t, tab, col0, n_live, pb, s); break;
-        case 5: rc = launch_chunk<TIN, 5>(p, waves, n, src, o, t, tab, col0, n_live, pb, s); break;
-        case 4: rc = launch_chunk<TIN, 4>(p, waves, n, src, o, t, tab, col0, n_live, pb, s); break;
-        case 3: rc = launch_chunk<TIN, 3>(p, waves, n, src, o, t, tab, col0, n_live, pb, s); break;
+        case 6: rc = launch_chunk<TIN, 6>(p, n, src, o, t, tab, col0, n_live, pb, s); break;
+        case 5: rc = launch_chunk<TIN, 5>(p, n, src, o, t, tab, col0, n_live, pb, s); break;
+        case 4: rc = launch_chunk<TIN, 4>(p, n, src, o, t, tab, col0, n_live, pb, s); break;
+        case 3: rc = launch_chunk<TIN, 3>(p, n, src, o, t, tab, col0, n_live, pb, s); break;
         default: return zk_fail(ZK_E_BADARG, "internal: direct chunk width");
       }
       if (rc) return rc;

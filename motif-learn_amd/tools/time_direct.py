@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the plain sum on the matrix cores (ZK_PATH_DIRECT: what ZK_PATH_AUTO runs from n_max 17), batch and dense, steady state.
-Switches: ZK_DIRECT_NO_ROLL=1 / 0 (whole-slab / rolling re-arm of the batch kernel's LDS slab), ZK_DIRECT_CH96=1 (96 functions per chunk
-for every set, round 3's form), ZK_DIRECT_FORM=8|4|0|1 (kernel form: csrc/zk_direct_patches.hip).   time_direct.py [--batch-only] [--patches N]"""
+Switch: ZK_DIRECT_CH96=1 (96 functions per chunk for every set, round 3's form).   time_direct.py [--batch-only] [--patches N]"""
 import os, sys, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "motif-learn_amd"))

@@ -873,11 +873,11 @@ def test_large_sets_two_implementations_of_the_plain_sum(native, zo, n_max, size
 
 @pytest.mark.parametrize("n_max,size,dtype,n_patches", [(20, 40, np.float32, 512 + 64 + 7), (19, 40, np.float64, 1100),
                                                         (13, 26, np.float32, 333), (24, 48, np.float32, 64)])
-def test_direct_batch_kernel_both_workgroup_shapes(native, zo, n_max, size, dtype, n_patches, monkeypatch):
-    """zk_patch_direct_kernel runs 8 waves per workgroup on batches that fill the chip and 4 below (ZK_DIRECT_WAVES forces
-    either): the same sums in the same order, so bit-identical, with whole waves past the end of the batch in the last
-    workgroup (they keep its barriers and store nothing), chunks of unequal width (231 functions = 5 + 5 + 5 blocks, 210 =
-    5 + 5 + 4, 105 = 4 + 3, 325 = 6 + 5 + 5 + 5) and NaNs outside the disk."""
+def test_direct_batch_kernel_ragged_batches_and_chunk_widths(native, zo, n_max, size, dtype, n_patches):
+    """zk_patch_direct_kernel: four waves of 64 patches per workgroup walk the table together, so the last workgroup of a
+    ragged batch holds whole waves past the end (they keep its barriers and store nothing) and a partly filled one; chunks of
+    unequal width (231 functions = 5 + 5 + 5 blocks of 16, 210 = 5 + 5 + 4, 105 = 4 + 3, 325 = 6 + 5 + 5 + 5); NaNs outside
+    the disk; rows behind the batch's results untouched."""
     import torch
     rng = np.random.default_rng(n_max + size + n_patches)
     z = _zps(n_max, size)
@@ -888,23 +888,18 @@ def test_direct_batch_kernel_both_workgroup_shapes(native, zo, n_max, size, dtyp
     dirty = p.copy()
     dirty[:, ~disk] = np.nan
     p_dev = torch.from_numpy(p).cuda()
-    got = {}
     try:
-        for waves in ("8", "4"):
-            monkeypatch.setenv("ZK_DIRECT_WAVES", waves)
-            got[waves] = plan.transform_patches(p)
-            np.testing.assert_array_equal(plan.transform_patches(dirty), got[waves], err_msg=waves)
-            out = torch.full((n_patches + 3, len(z.n)), -7.0, dtype=torch.float64, device="cuda")
-            plan.transform_patches_dev(p_dev.data_ptr(), native.dtype_code(np.dtype(dtype)), n_patches, out.data_ptr())
-            torch.cuda.synchronize()
-            out = out.cpu().numpy()                 # rows past the batch stay untouched
-            assert (out[n_patches:] == -7.0).all()
-            np.testing.assert_array_equal(out[:n_patches], got[waves])
+        got = plan.transform_patches(p)
+        np.testing.assert_array_equal(plan.transform_patches(dirty), got)
+        out = torch.full((n_patches + 3, len(z.n)), -7.0, dtype=torch.float64, device="cuda")
+        plan.transform_patches_dev(p_dev.data_ptr(), native.dtype_code(np.dtype(dtype)), n_patches, out.data_ptr())
+        torch.cuda.synchronize()
+        out = out.cpu().numpy()
+        assert (out[n_patches:] == -7.0).all()
+        np.testing.assert_array_equal(out[:n_patches], got)
     finally:
-        monkeypatch.delenv("ZK_DIRECT_WAVES", raising=False)
         plan.set_path(native.PATH_AUTO)
-    np.testing.assert_array_equal(got["8"], got["4"])
-    rel_close(got["8"], zo.moments_patches(p, z.polynomials))
+    rel_close(got, zo.moments_patches(p, z.polynomials))
 
 
 def test_hbm_probe_reports_plausible_stream_rates(native):
