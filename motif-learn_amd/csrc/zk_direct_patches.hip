@@ -131,10 +131,9 @@ __device__ __forceinline__ void zk_static_for(F&& f) {
 }
 
 template <typename TIN, int FB>
-__global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __restrict__ in, double* __restrict__ out,
-                                                                          const zk_direct_unit* __restrict__ units,
-                                                                          const double* __restrict__ tab, int n_units, int col0,
-                                                                          int n_live, int n_poly, long long n_patches, int patch_bytes) {
+__device__ __forceinline__ void zk_patch_direct_chunk(const TIN* __restrict__ in, double* __restrict__ out,
+                                                      const zk_direct_unit* __restrict__ units, const double* __restrict__ tab, int n_units,
+                                                      int col0, unsigned patch_block, int n_poly, long long n_patches, int patch_bytes) {
   typedef double v4d __attribute__((ext_vector_type(4)));
   constexpr int CH = 16 * FB;
   constexpr int PXG = 16 / sizeof(TIN);  // steps per run: 4 (float32) or 2 (float64)
@@ -147,7 +146,8 @@ __global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __re
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr int WAVES = 4;
   char* const ring = (char*)lds + WAVES * 12288;  // the waves' slabs (three 4-KiB run images each), then the two table pieces
-  const long long patch0 = ((long long)blockIdx.x * WAVES + wave) * 64;
+  const int n_live = n_poly - col0 < CH ? n_poly - col0 : CH;
+  const long long patch0 = ((long long)patch_block * WAVES + wave) * 64;
   const long long left = n_patches - patch0;
   // a wave past the end of the batch keeps the workgroup's barriers and its share of the table DMA: it reads patch 0, stores nothing
   const int nv = left <= 0 ? 0 : left < 64 ? (int)left : 64;
@@ -282,50 +282,64 @@ __global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __re
     }
 }
 
+// One launch = every chunk over all patches, chunk after chunk (workgroup index = chunk * blocks_per_chunk + patch block): a small
+// batch fills as many CUs as it has chunks times workgroups, and no chunk waits for the tail of the one before it.  The first n_hi
+// chunks hold FB blocks of 16 functions, the others FB - 1 (their tables follow the wider ones').
 template <typename TIN, int FB>
-int launch_chunk(zk_plan* p, int64_t n, const TIN* src, double* out, const zk_direct_tables::per_type& t, const double* tab, int col0,
-                 int n_live, int patch_bytes, hipStream_t s) {
+__global__ __launch_bounds__(256, 2) void zk_patch_direct_kernel(const TIN* __restrict__ in, double* __restrict__ out,
+                                                                 const zk_direct_unit* __restrict__ units,
+                                                                 const double* __restrict__ tab, int n_units, int n_hi,
+                                                                 unsigned blocks_per_chunk, int n_poly, long long n_patches,
+                                                                 int patch_bytes) {
+  constexpr int UP = 64 / (int)sizeof(TIN);
+  const int chunk = (int)(blockIdx.x / blocks_per_chunk);
+  const unsigned patch_block = blockIdx.x - (unsigned)chunk * blocks_per_chunk;
+  const size_t rows = (size_t)n_units * (4 * UP);  // table rows of a chunk
+  if (chunk < n_hi)
+    zk_patch_direct_chunk<TIN, FB>(in, out, units, tab + (size_t)chunk * rows * (16 * FB), n_units, chunk * 16 * FB, patch_block, n_poly,
+                                   n_patches, patch_bytes);
+  else
+    zk_patch_direct_chunk<TIN, FB - 1>(in, out, units, tab + (size_t)n_hi * rows * (16 * FB) + (size_t)(chunk - n_hi) * rows * (16 * (FB - 1)),
+                                       n_units, n_hi * 16 * FB + (chunk - n_hi) * 16 * (FB - 1), patch_block, n_poly, n_patches, patch_bytes);
+}
+
+template <typename TIN, int FB>
+int launch_fb(zk_plan* p, int64_t n, const TIN* src, double* out, const zk_direct_tables::per_type& t, int patch_bytes, hipStream_t s) {
+  const zk_direct_tables* d = p->direct;
   constexpr int PIECE = (int)(16 / sizeof(TIN) / 2) * FB * 1024;
   const int lds = 4 * 12288 + 2 * PIECE;  // <= 72 KiB: two workgroups per CU
   auto kern = zk_patch_direct_kernel<TIN, FB>;
   ZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, s, src, out, t.d_units, tab, t.n_units, col0, n_live,
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  int rc = zk_prof_begin(p, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3(blocks * (unsigned)d->n_chunks), dim3(256), lds, s, src, out, t.d_units, t.d_tab, t.n_units, d->n_hi, blocks,
                      p->n_poly, (long long)n, patch_bytes);
   ZK_HIP(hipGetLastError());
-  return 0;
+  return zk_prof_end(p, s);
 }
 
 template <typename TIN>
 int launch_t(zk_plan* p, const void* in, int64_t n_patches, double* out, hipStream_t s) {
   const zk_direct_tables* d = p->direct;
   const zk_direct_tables::per_type& t = d->t[sizeof(TIN) == 4 ? 0 : 1];
-  constexpr int UP = 64 / (int)sizeof(TIN);
   const size_t patch_elems = (size_t)p->size * p->size;
-  // (every chunk's launch streams the patches again: 8 x 20.7 KB per patch at (72, 36) against 5.5 MFLOP -- a quarter of the
-  //  arithmetic's time at the HBM rate, and it overlaps)
-  const int64_t round_max = (int64_t)1 << 22;
+  const int pb = (int)(patch_elems * sizeof(TIN));
+  // (every chunk streams the patches again: 8 x 20.7 KB per patch at (72, 36) against 5.5 MFLOP -- a quarter of the arithmetic's
+  //  time at the HBM rate, and it overlaps)
+  const int64_t round_max = (int64_t)1 << 20;  // (x up to 11 chunks: the grid stays far below 2^31 workgroups)
   for (int64_t first = 0; first < n_patches; first += round_max) {
     const int64_t n = std::min<int64_t>(n_patches - first, round_max);
     const TIN* src = (const TIN*)in + first * patch_elems;
-    const double* tab = t.d_tab;
-    for (int c = 0; c < d->n_chunks; ++c) {
-      const int fb = d->chunk_fb(c), col0 = d->chunk_col0(c);
-      const int n_live = std::min(16 * fb, p->n_poly - col0);
-      int rc = zk_prof_begin(p, s);
-      if (rc) return rc;
-      double* o = out + first * p->n_poly;
-      const int pb = (int)(patch_elems * sizeof(TIN));
-      switch (fb) {
-        case 6: rc = launch_chunk<TIN, 6>(p, n, src, o, t, tab, col0, n_live, pb, s); break;
-        case 5: rc = launch_chunk<TIN, 5>(p, n, src, o, t, tab, col0, n_live, pb, s); break;
-        case 4: rc = launch_chunk<TIN, 4>(p, n, src, o, t, tab, col0, n_live, pb, s); break;
-        case 3: rc = launch_chunk<TIN, 3>(p, n, src, o, t, tab, col0, n_live, pb, s); break;
-        default: return zk_fail(ZK_E_BADARG, "internal: direct chunk width");
-      }
-      if (rc) return rc;
-      if ((rc = zk_prof_end(p, s))) return rc;
-      tab += (size_t)t.n_units * 4 * UP * 16 * fb;
+    double* o = out + first * p->n_poly;
+    int rc;
+    switch (d->fb_hi) {
+      case 6: rc = launch_fb<TIN, 6>(p, n, src, o, t, pb, s); break;
+      case 5: rc = launch_fb<TIN, 5>(p, n, src, o, t, pb, s); break;
+      case 4: rc = launch_fb<TIN, 4>(p, n, src, o, t, pb, s); break;
+      default: return zk_fail(ZK_E_BADARG, "internal: direct chunk width");
     }
+    if (rc) return rc;
   }
   return 0;
 }

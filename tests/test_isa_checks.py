@@ -23,10 +23,10 @@ def test_hand_issued_requests_have_no_register_hazards(tmp_path):
 
 def test_direct_batch_kernel_operand_reads_have_no_register_hazards(tmp_path):
     """zk_patch_direct_kernel reads its MFMA operands (pixels and table rows) from LDS a step ahead, by asm reads into a second set
-    of registers: 2 input types x 4 chunk widths."""
+    of registers: 2 input types x 3 widths of the wider chunks (each kernel also holds the body one block narrower)."""
     asm = tmp_path / "direct.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I../../include", "-I.", "-S",
                            "--cuda-device-only", "-o", str(asm), "zk_direct_patches.hip"], cwd=CSRC, stderr=subprocess.DEVNULL)
     out = subprocess.run([sys.executable, CHECK, str(asm)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-3000:]
-    assert "8 kernel(s) with hand-issued requests checked, 0 hazard(s)" in out.stdout
+    assert "6 kernel(s) with hand-issued requests checked, 0 hazard(s)" in out.stdout
