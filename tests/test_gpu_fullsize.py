@@ -219,3 +219,29 @@ def test_one_ranks_share_of_the_frame_batch():
     ri, ci = torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev)
     for i in (0, per_rank - 1):
         rel_close(full[i][:, ri, ci].T.cpu().numpy(), _oracle_at(zo, host[i], z, rows, cols))
+
+
+def test_direct_batch_beyond_one_round_of_launches():
+    """zk_patch_direct_kernel takes 2^20 patches per launch (all chunks of the set in it): a batch of 2^20 + 300 needs a second
+    round whose patch and result offsets must line up.  Rows on both sides of the seam equal the same patches transformed on
+    their own (bit for bit: same sums in the same order) and the oracle's plain sum."""
+    import torch
+    from oracle import zernike_oracle as zo
+    from mtflearn_amd import _native as native, distributed as D
+    z = _zps(13, 20)                                      # 105 functions = 4 + 3 blocks of 16: both bodies of the kernel
+    plan = z._device_plan()
+    plan.set_path(native.PATH_DIRECT)
+    try:
+        n = (1 << 20) + 300
+        g = torch.Generator(device="cuda").manual_seed(1)
+        p = torch.rand((n, 20, 20), device="cuda", generator=g, dtype=torch.float32)
+        out = D.patch_moments_device(plan, p)
+        idx = torch.from_numpy(np.r_[0:200, (1 << 20) - 200:(1 << 20) + 300]).cuda()
+        sub = p[idx].contiguous()
+        alone = D.patch_moments_device(plan, sub)
+        torch.cuda.synchronize()
+        got = out[idx].cpu().numpy()
+        np.testing.assert_array_equal(got, alone.cpu().numpy())
+        rel_close(got, zo.moments_patches(sub.cpu().numpy(), z.polynomials))
+    finally:
+        plan.set_path(native.PATH_AUTO)
