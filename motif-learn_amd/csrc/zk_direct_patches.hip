@@ -1,11 +1,13 @@
 // zk_direct_patches.hip -- batch-of-patches moments as the plain sum the reference computes (_zps.py:146-157: np.dot of the
 // flattened patch with the flattened basis), every disk pixel times the CALLER'S number for it, for function sets too large
-// for a lane's registers and beyond the reach of the polynomial kernels: n_max 25 .. 40 (351 .. 861 functions), which is what
-// the reference's own estimator returns for 56 .. 72-px patches (features/_estimate_n_max.py:95,123).
+// for a lane's registers and beyond the reach of the polynomial kernels: what ZK_PATH_AUTO runs from n_max 17 (171 .. 861
+// functions up to n_max 40 -- the orders the reference's own estimator returns for 40 .. 72-px patches,
+// features/_estimate_n_max.py:95,123) and for any other set of >= 92 functions.
 //
-// Why not cheaper arithmetic: above n_max ~24 the reference's float64 basis is neither the exact polynomial (2e-4 of max|V| off
-// at 36) nor mirror-symmetric (8e-4 at 36), so neither the row-separable nor a mirror-folded sum restates the reference's result
-// to 1e-6 (profiles/r03_high_orders.txt).  What is left is the product itself: (patches x pixels) . (pixels x functions), 1 to
+// Why not cheaper arithmetic: on structured inputs the polynomial kernels leave the reference's outputs by more than SURVEY
+// 8(c)'s criterion from n_max 20-22 (profiles/r04_high_orders.txt), and above n_max ~24 the reference's float64 basis is neither
+// the exact polynomial (2e-4 of max|V| off at 36) nor mirror-symmetric (8e-4 at 36), so neither the row-separable nor a
+// mirror-folded sum restates the reference's result to 1e-6 (profiles/r03_high_orders.txt).  What is left is the product itself: (patches x pixels) . (pixels x functions), 1 to
 // 3 MFLOP per patch -- a GEMM, compute-bound by a wide margin (arithmetic intensity in the hundreds of flop per byte; the
 // 32-px / n_max 8 headline path is the opposite case and stays off the matrix cores).  zk_generic_kernel's batch mode ran it
 // at 3 % of the FP64 peak (an uncoalesced 4-byte load per lane and pixel, waited for, then 64 FMAs on scalar operands that miss
@@ -24,8 +26,8 @@
 //   / area, zero rows where a run overlaps its neighbour or leaves the disk -- every disk pixel is owned by exactly one slot,
 //   checked at plan creation; steps whose four rows are all zero are skipped).  The rows reach the waves through LDS: a
 //   workgroup's waves walk the runs together and share one copy (below);
-//   the functions are done CH at a time: one launch per chunk over the same patches; results go straight into the
-//   (N, n_poly) rows (16 consecutive functions per 128-B segment).
+//   the functions are done CH at a time, every chunk over the same patches, all chunks in one launch (workgroup = (chunk,
+//   256 patches)); results go straight into the (N, n_poly) rows (16 consecutive functions per 128-B segment).
 #include <math.h>
 #include <stdlib.h>
 
