@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/zps_high_golden.npz from the REFERENCE implementation (build container only): the orders its own
+estimator returns for 56 .. 72-px windows (``features/_estimate_n_max.py:95,123``: up to size / 2), where the build runs the
+plain sum on the matrix cores (csrc/zk_direct_patches.hip) and where the reference's float64 basis is neither the exact
+polynomial nor point-symmetric any more.
+
+TEST INFRASTRUCTURE, same rules as oracle/make_golden.py (whose loader this uses): reference outputs recorded as plain
+arrays, structured inputs (the reference's own test blobs + windows / a crop of a honeycomb lattice), batch path
+(``_zps.py:146-157``) and dense path (``_zps.py:159-193``) on a float64-cast crop -- strided positions incl. both zero-padded
+borders, per-plane sums over ALL positions.  threadpoolctl pins BLAS to one thread so that the file regenerates bit for bit.
+
+Usage:  python oracle/make_golden_high_orders.py
+"""
+import os
+
+import numpy as np
+from threadpoolctl import threadpool_limits
+
+from make_golden import import_reference, sample_index
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "zps_high_golden.npz")
+HIGH_ORDERS = ((28, 56), (32, 64), (36, 72))
+
+
+def main():
+    import warnings
+    ZPs, _zm, get_patches, HoneyComb = import_reference()
+    lattice = HoneyComb(size=256, l=12, seed=11).to_image()                      # float32 (256, 256)
+    g = {}
+    with threadpool_limits(1), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for n_max, K in HIGH_ORDERS:
+            z = ZPs(n_max, K)
+            tag = f"{n_max}_{K}"
+            blobs = np.concatenate([get_patches(size=K, n_fold=3, num_patches=3), get_patches(size=K, n_fold=6, num_patches=2)])
+            crops = np.array([lattice[r:r + K, c:c + K] for r in range(7, 256 - K, 83) for c in range(2, 256 - K, 71)])
+            batch = np.ascontiguousarray(np.concatenate([blobs, crops]).astype(np.float32))
+            g[f"hi_batch_{tag}"] = batch
+            g[f"hi_Z_{tag}"] = z.transform(batch).data
+            H, W = K + 9, K + 14
+            crop = np.ascontiguousarray(lattice[30:30 + H, 50:50 + W])
+            g[f"hi_frame_{tag}"] = crop
+            Zf = z.transform(crop.astype(np.float64)).data
+            ri, ci = sample_index(H, 8), sample_index(W, 9)
+            g[f"hi_Zf_{tag}"] = Zf[:, ri][:, :, ci]
+            g[f"hi_Zf_sum_{tag}"] = Zf.sum(axis=(1, 2))
+            g[f"hi_Zf_max_{tag}"] = np.abs(Zf).max()
+            print(tag, batch.shape, g[f"hi_Z_{tag}"].shape, g[f"hi_Zf_{tag}"].shape)
+    np.savez(OUT, **g)
+    print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB,", len(g), "arrays")
+
+
+if __name__ == "__main__":
+    main()

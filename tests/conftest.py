@@ -21,6 +21,13 @@ def golden():
         return {k: f[k] for k in f.files}
 
 
+@pytest.fixture(scope="session")
+def golden_high():
+    """Reference outputs at n_max 28 / 32 / 36 on structured inputs (oracle/make_golden_high_orders.py)."""
+    with np.load(os.path.join(ROOT, "tests", "golden", "zps_high_golden.npz")) as f:
+        return {k: f[k] for k in f.files}
+
+
 def rel_close(got, ref, rtol=1e-6, atol_scale=1e-12):
     """Parity criterion of SURVEY 8c: elementwise rtol=1e-6 with an absolute floor of
     1e-12 * max|ref| that only matters for moments that cancel to ~0."""

@@ -968,6 +968,31 @@ def test_auto_path_against_reference_on_structured_inputs(native, golden, n_max,
             rel_close(res, want, atol_scale=_floor(name, n_max))
 
 
+@pytest.mark.parametrize("n_max,size", [(28, 56), (32, 64), (36, 72)])
+def test_high_orders_against_reference(native, golden_high, n_max, size):
+    """n_max 28 / 32 / 36 on 56 / 64 / 72-px windows (what the reference's estimator returns there) against REFERENCE outputs
+    on structured inputs (oracle/make_golden_high_orders.py: hi_*), SURVEY 8c's criterion verbatim with the floor of 1e-11
+    max|Z|: ZK_PATH_AUTO = the plain sum on the matrix cores, batch (whole waves and a ragged one) and dense (float64-cast
+    crop, strided positions incl. the zero-padded borders, per-plane sums); fewer than 64 patches = the per-lane kernel."""
+    g, tag = golden_high, f"{n_max}_{size}"
+    z = _zps(n_max, size)
+    plan = z._device_plan()
+    batch, ref = np.ascontiguousarray(g[f"hi_batch_{tag}"]), g[f"hi_Z_{tag}"]
+    rel_close(z.transform(batch).data, ref, atol_scale=1e-11)                       # 14 patches: the per-lane kernel
+    big = np.ascontiguousarray(np.concatenate([batch] * 10))                        # 140 patches: two waves and a ragged one
+    assert plan.best_path(0, native.ZK_F32, len(big)) == native.PATH_DIRECT and plan.best_path(1, native.ZK_F64) == native.PATH_DIRECT
+    got = z.transform(big).data
+    for k in range(10):
+        rel_close(got[k * len(batch):(k + 1) * len(batch)], ref, atol_scale=1e-11)
+    crop = g[f"hi_frame_{tag}"].astype(np.float64)
+    H, W = crop.shape
+    dense = z.transform(crop).data
+    rel_close(dense[:, _sample_index(H, 8)][:, :, _sample_index(W, 9)], g[f"hi_Zf_{tag}"], atol_scale=1e-11)
+    mx = float(g[f"hi_Zf_max_{tag}"])
+    np.testing.assert_allclose(dense.sum(axis=(1, 2)), g[f"hi_Zf_sum_{tag}"], rtol=1e-9, atol=1e-11 * H * W * mx)
+    np.testing.assert_array_equal(z.transform(g[f"hi_frame_{tag}"]).data, dense)   # the float32 crop: the cast is exact
+
+
 def test_config0_frame_against_reference(native, golden):
     """configs[0]: the reference's own 512 x 512 test image (datasets/_zps_test_data.py:62-65, seed 0), 32-px patches,
     n_max 8 -- the batch path on a strided grid of windows and the dense path on the whole frame against reference outputs."""
