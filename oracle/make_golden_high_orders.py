@@ -46,6 +46,18 @@ def main():
             g[f"hi_Zf_sum_{tag}"] = Zf.sum(axis=(1, 2))
             g[f"hi_Zf_max_{tag}"] = np.abs(Zf).max()
             print(tag, batch.shape, g[f"hi_Z_{tag}"].shape, g[f"hi_Zf_{tag}"].shape)
+        # the reference's own tail (zmoments.rot_maps / |to_complex| / mirror_map, _zmoments.py:300-316, 420-493) of its dense
+        # moments where the build takes them from the matrix-core kernel: n_max 20 (fused band kernel) and 28 (planes tail)
+        for n_max, K in ((20, 40), (28, 56)):
+            tag = f"{n_max}_{K}"
+            crop = np.ascontiguousarray(lattice[90:90 + K + 7, 20:20 + K + 12])
+            g[f"hi_maps_frame_{tag}"] = crop
+            zm = ZPs(n_max, K).transform(crop.astype(np.float64))
+            ri, ci = sample_index(crop.shape[0], 6), sample_index(crop.shape[1], 7)
+            g[f"hi_maps_rot_{tag}"] = zm.rot_maps([2, 3, 4, 6])[:, ri][:, :, ci]
+            g[f"hi_maps_abs_{tag}"] = np.abs(zm.to_complex().data)[:, ri][:, :, ci]
+            g[f"hi_maps_mirror_{tag}"] = zm.mirror_map()[ri][:, ci]
+            print("maps", tag, g[f"hi_maps_abs_{tag}"].shape)
     np.savez(OUT, **g)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB,", len(g), "arrays")
 

@@ -1042,6 +1042,23 @@ def test_fused_symmetry_maps_against_reference_on_a_structured_crop(native, gold
         np.testing.assert_allclose(pick(zm.mirror_map()), golden["st_maps_mirror_10_32"], rtol=1e-8, atol=1e-11)
 
 
+@pytest.mark.parametrize("n_max,size", [(20, 40), (28, 56)])
+def test_symmetry_maps_at_high_orders_against_reference(native, golden_high, n_max, size):
+    """ZPs.symmetry_maps where the moments come from the matrix-core kernel (n_max 20: a band of them feeds the class-pass tail;
+    28: the planes tail) against the REFERENCE's own rot_maps / |to_complex| / mirror_map of its dense moments of a honeycomb crop
+    (oracle/make_golden_high_orders.py: hi_maps_*), float32 and float64 in."""
+    g, tag = golden_high, f"{n_max}_{size}"
+    z = _zps(n_max, size)
+    crop = g[f"hi_maps_frame_{tag}"]
+    ri, ci = _sample_index(crop.shape[0], 6), _sample_index(crop.shape[1], 7)
+    pick = lambda a: a[..., ri, :][..., ci]
+    for img in (crop, crop.astype(np.float64)):
+        maps = z.symmetry_maps(img)
+        np.testing.assert_allclose(pick(maps["rot_maps"]), g[f"hi_maps_rot_{tag}"], rtol=1e-8, atol=1e-11)
+        rel_close(pick(maps["abs"]), g[f"hi_maps_abs_{tag}"], rtol=1e-8, atol_scale=1e-11)
+        np.testing.assert_allclose(pick(maps["mirror_map"]), g[f"hi_maps_mirror_{tag}"], rtol=1e-8, atol=1e-11)
+
+
 def test_keypoints_moments_against_the_reference(native):
     """mtflearn_amd.features.KeyPoints (the reference's class, features/_keypoint.py:53-92): border clearing + windows as the
     reference cuts them, and `moments(zps)` -- the windows read from the resident frame on the GPU -- against the REFERENCE's

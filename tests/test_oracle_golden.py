@@ -224,3 +224,18 @@ def test_symmetry_tail_goldens_on_a_structured_crop(golden):
     np.testing.assert_allclose(pick(zo.mirror_map(mom, n, m)), golden["st_maps_mirror_10_32"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(pick(zo.rot_maps(mom, n, m, [3, 5], p=None, m_unselect=(0, 1, 2))),
                                golden["st_maps_rot_pnone_unsel012_10_32"], rtol=1e-9, atol=1e-14)
+
+
+@pytest.mark.parametrize("n_max,size", [(20, 40), (28, 56)])
+def test_high_order_symmetry_tail_goldens(golden_high, n_max, size):
+    """The reference's rot_maps / |to_complex| / mirror_map of its own dense moments at n_max 20 and 28 (where the build takes the
+    moments from the matrix-core kernel): the oracle's tail on the oracle's (convolution-form) moments restates them."""
+    g, tag = golden_high, f"{n_max}_{size}"
+    n, m, b = zo.zernike_basis(n_max, size)
+    crop = g[f"hi_maps_frame_{tag}"].astype(np.float64)
+    mom = zo.moments_frame_direct(crop, zo.convolution_basis(b, n))
+    ri, ci = sample_index(crop.shape[0], 6), sample_index(crop.shape[1], 7)
+    pick = lambda a: a[..., ri, :][..., ci]
+    np.testing.assert_allclose(pick(zo.rot_maps(mom, n, m, [2, 3, 4, 6])), g[f"hi_maps_rot_{tag}"], rtol=1e-8, atol=1e-11)
+    rel_close(pick(np.abs(zo.to_complex(mom, n, m)[0])), g[f"hi_maps_abs_{tag}"], rtol=1e-8, atol_scale=1e-11)
+    np.testing.assert_allclose(pick(zo.mirror_map(mom, n, m)), g[f"hi_maps_mirror_{tag}"], rtol=1e-8, atol=1e-11)
