@@ -58,6 +58,17 @@ def main():
             g[f"hi_maps_abs_{tag}"] = np.abs(zm.to_complex().data)[:, ri][:, :, ci]
             g[f"hi_maps_mirror_{tag}"] = zm.mirror_map()[ri][:, ci]
             print("maps", tag, g[f"hi_maps_abs_{tag}"].shape)
+        # moments at key points at an order the matrix-core kernel serves: the reference's KeyPoints (features/_keypoint.py:53-78:
+        # border clearing, windows cut around the rounded points) + its ZPs(20, 40).transform of those windows
+        import make_golden_keypoints
+        kp, ZPs2, HoneyComb2 = make_golden_keypoints.import_reference()
+        rng = np.random.default_rng(20261006)
+        frame = HoneyComb2(size=200, l=12, seed=5).to_image()[:180]                   # (180, 200) float32
+        pts = np.column_stack([rng.uniform(-5, 205, 260), rng.uniform(-5, 185, 260)])
+        k = kp.KeyPoints(pts, frame, 40)
+        g["hi_kp_frame"], g["hi_kp_pts"], g["hi_kp_kept_40"] = frame, pts, k.pts
+        g["hi_kp_Z_20_40"] = ZPs2(20, 40).transform(k.extract_patches()).data
+        print("key points", g["hi_kp_kept_40"].shape, g["hi_kp_Z_20_40"].shape)
     np.savez(OUT, **g)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB,", len(g), "arrays")
 

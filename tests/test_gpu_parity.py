@@ -1077,6 +1077,21 @@ def test_keypoints_moments_against_the_reference(native):
         rel_close(z.transform(kp.extract_patches()).data, kg[f"Z_{size}"])          # the batch route: same numbers
 
 
+def test_keypoints_moments_at_a_high_order_against_the_reference(native, golden_high):
+    """The same at n_max 20 on 40-px windows (123 points kept of 260): `KeyPoints.moments` gathers the windows on the device and runs
+    the matrix-core plain sum; against the REFERENCE's ZPs(20, 40).transform of the windows its own KeyPoints cut."""
+    from mtflearn_amd.features import KeyPoints
+    g = golden_high
+    kp = KeyPoints(g["hi_kp_pts"], g["hi_kp_frame"], 40)
+    np.testing.assert_array_equal(kp.pts, g["hi_kp_kept_40"])
+    z = _zps(20, 40)
+    zm = kp.moments(z)
+    assert zm.data.shape == g["hi_kp_Z_20_40"].shape
+    rel_close(zm.data, g["hi_kp_Z_20_40"], atol_scale=1e-11)
+    rel_close(z.transform(kp.extract_patches()).data, g["hi_kp_Z_20_40"], atol_scale=1e-11)
+    assert z._device_plan().best_path(0, native.ZK_F32, len(kp.pts)) == native.PATH_DIRECT
+
+
 def test_auto_never_takes_the_polynomial_kernels_above_n_max_16(native, zo):
     """A window too large for the matrix-core dense kernel's LDS tile (float64, 106 px: 155 KB) but not for the separable kernel's
     (147 KB), at an order AUTO serves with the plain sum: the per-lane plain sum runs instead of the separable family -- slow, and
