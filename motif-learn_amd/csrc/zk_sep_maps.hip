@@ -470,6 +470,25 @@ int ZK_GROUP_FN(zk_maps_rows_dispatch)(zk_plan* p, const double* mom, int64_t n_
   return zk_fail(ZK_E_BADARG, "no symmetry-map rows kernel for this n_max");
 }
 
+#if ZK_NMAX_GROUP >= 2
+// Rows of a band whose moments come from zk_frame_direct_kernel (a workgroup = 8 output rows x 64 columns, one workgroup per CU at
+// a time): of the multiples of 8 between half the scratch limit and the limit, the one whose grid fills whole rounds of the chip's
+// CUs best -- 88 rows of a 2048-wide frame are 352 workgroups = 1.4 rounds on 256 CUs (the time of two), 64 rows are one round.
+static int64_t zk_direct_band_rows(const zk_plan* p, int64_t W, int64_t limit, int64_t n_rows) {
+  if (limit >= n_rows) return n_rows;
+  const int64_t cb = (W + 63) / 64, top = limit / 8 * 8;
+  if (top <= 8) return 8;
+  int64_t best = top;
+  double best_fill = 0.0;
+  for (int64_t r = top; r >= 8 && 2 * r > top; r -= 8) {
+    const int64_t blocks = r / 8 * cb, rounds = (blocks + p->n_cu - 1) / p->n_cu;
+    const double fill = (double)blocks / (double)(rounds * p->n_cu);
+    if (fill > best_fill + 1e-9) best_fill = fill, best = r;
+  }
+  return best;
+}
+#endif
+
 #if ZK_NMAX_GROUP == 2
 // n_max 17-20: the moments of a row band come from the class-pass dense kernel into the plan's scratch
 // matrix (<= 1 GiB at a time), the planes kernel turns them into the maps of those rows.
@@ -480,6 +499,7 @@ int zk_maps_planes_g2(zk_plan* p, const void* in, int dtype, int64_t H, int64_t 
   //  28.8 ms with 1-GiB bands, 45 ms at 256 MiB, 187 ms at 32 MiB)
   int64_t band = (int64_t)((size_t)1 << 30) / ((int64_t)p->n_poly * W * (int64_t)sizeof(double));
   band = band < 8 ? 8 : (band > n_rows ? n_rows : band);
+  if (p->path != ZK_PATH_SEPARABLE && zk_plan_auto_direct(p, 1, dtype) && !getenv("ZK_NO_DIRECT")) band = zk_direct_band_rows(p, W, band, n_rows);
   const size_t need = (size_t)p->n_poly * band * W * sizeof(double);
   if (p->d_scratch_bytes < need) {
     if (p->d_scratch) ZK_HIP(hipFree(p->d_scratch));
@@ -533,6 +553,7 @@ int zk_maps_planes_large(zk_plan* p, int knm, const void* in, int dtype, int64_t
                       hipStream_t s) {
   int64_t band = (int64_t)((size_t)1 << 30) / ((int64_t)p->n_poly * W * (int64_t)sizeof(double));
   band = band < 8 ? 8 : (band > n_rows ? n_rows : band);
+  band = zk_direct_band_rows(p, W, band, n_rows);
   const size_t need = (size_t)p->n_poly * band * W * sizeof(double);
   if (p->d_scratch_bytes < need) {
     if (p->d_scratch) ZK_HIP(hipFree(p->d_scratch));
